@@ -1,0 +1,117 @@
+"""ctypes binding of libaptp_hip.so (C ABI declared in include/aptp_hip.h).
+
+The library is the ONLY compute path of this package: there is no PyTorch/CPU fallback.  Loading fails loudly if
+the shared object is missing (build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``make -C diffusion_pruning_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libaptp_hip.so")
+
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+TILE_AUTO, TILE_128x128, TILE_128x160, TILE_64x128, TILE_64x160, TILE_128x64, TILE_64x64 = range(7)
+
+
+class ConvGemmParams(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64),
+        ("B", c_int32), ("Hin", c_int32), ("Win", c_int32), ("Cin", c_int32),
+        ("Hout", c_int32), ("Wout", c_int32),
+        ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32), ("ups", c_int32),
+        ("w", c_void_p),
+        ("N", c_int32), ("cin_pad", c_int32),
+        ("bias", c_void_p),
+        ("rowbias", c_void_p), ("ld_rowbias", c_int32),
+        ("colgate", c_void_p), ("gate_group", c_int32), ("gate_B", c_int32),
+        ("act", c_int32),
+        ("corr", c_void_p), ("corr_B", c_int32),
+        ("residual", c_void_p), ("ldres", c_int64),
+        ("depth", c_void_p), ("depth_B", c_int32),
+        ("depth_in", c_void_p), ("lddin", c_int64),
+        ("y", c_void_p), ("ldy", c_int64),
+        ("out_f32", c_int32), ("split_k", c_int32),
+        ("workspace", c_void_p),
+        ("tile", c_int32),
+    ]
+
+
+class GroupNormParams(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64),
+        ("y", c_void_p), ("ldy", c_int64),
+        ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("groups", c_int32),
+        ("gamma", c_void_p), ("beta", c_void_p),
+        ("eps", c_float), ("silu", c_int32),
+        ("workspace", c_void_p),
+    ]
+
+
+class LayerNormParams(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64),
+        ("y", c_void_p), ("ldy", c_int64),
+        ("rows", c_int32), ("C", c_int32),
+        ("gamma", c_void_p), ("beta", c_void_p),
+        ("eps", c_float),
+    ]
+
+
+class AttentionParams(Structure):
+    _fields_ = [
+        ("q", c_void_p), ("q_stride_b", c_int64), ("q_stride_l", c_int64),
+        ("k", c_void_p), ("k_stride_b", c_int64), ("k_stride_l", c_int64),
+        ("v", c_void_p), ("v_stride_b", c_int64), ("v_stride_l", c_int64),
+        ("o", c_void_p), ("o_stride_b", c_int64), ("o_stride_l", c_int64),
+        ("B", c_int32), ("heads", c_int32), ("Lq", c_int32), ("Lk", c_int32),
+        ("scale", c_float),
+    ]
+
+
+# every symbol include/aptp_hip.h declares: (name, restype, argtypes)
+EXPORTS = [
+    ("aptp_conv_gemm", c_int, [POINTER(ConvGemmParams), c_void_p]),
+    ("aptp_conv_gemm_workspace_bytes", c_int64, [POINTER(ConvGemmParams)]),
+    ("aptp_conv_gemm_suggest_split_k", c_int, [POINTER(ConvGemmParams)]),
+    ("aptp_groupnorm", c_int, [POINTER(GroupNormParams), c_void_p]),
+    ("aptp_groupnorm_nchunk", c_int, [c_int]),
+    ("aptp_groupnorm_workspace_bytes", c_int64, [POINTER(GroupNormParams)]),
+    ("aptp_layernorm", c_int, [POINTER(LayerNormParams), c_void_p]),
+    ("aptp_attention", c_int, [POINTER(AttentionParams), c_void_p]),
+    ("aptp_last_error", c_char_p, []),
+    ("aptp_version", c_int, []),
+]
+
+_lib = None
+
+
+class AptpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libaptp_hip.so (once) and declare the prototypes.  Raises if the library is missing: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AptpError(
+            f"{LIB_PATH} not found: the HIP extension is the only compute path of diffusion_pruning_amd. "
+            "Build it with `make -C diffusion_pruning_amd/csrc` (hipcc, --offload-arch=gfx950).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().aptp_last_error()
+        raise AptpError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,60 @@
+// Shared device/host helpers for libaptp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "aptp_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define APTP_WAVE 64
+
+void aptp_set_error(const char* fmt, ...);
+
+#define APTP_CHECK(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      aptp_set_error(__VA_ARGS__);       \
+      return APTP_EINVAL;                \
+    }                                    \
+  } while (0)
+
+#define APTP_LAUNCH_CHECK()                                              \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      aptp_set_error("launch failed: %s", hipGetErrorString(e__));       \
+      return APTP_ELAUNCH;                                               \
+    }                                                                    \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  union { __bf16 h[2]; uint32_t u; } r;
+  r.h[0] = (__bf16)a;
+  r.h[1] = (__bf16)b;
+  return r.u;
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4& q, float* f) {
+  union { uint4 q; __bf16 h[8]; } u;
+  u.q = q;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)u.h[i];
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
+  uint4 q;
+  q.x = pack_bf16x2(f[0], f[1]);
+  q.y = pack_bf16x2(f[2], f[3]);
+  q.z = pack_bf16x2(f[4], f[5]);
+  q.w = pack_bf16x2(f[6], f[7]);
+  return q;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -1,0 +1,211 @@
+// Flash-style scaled-dot-product attention, head_dim 64, bf16 in/out, fp32 softmax state (gfx950).
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.  Per 64-key tile:
+//   S^T[key][q] = K . Q^T      (mfma_f32_32x32x16_bf16, K fragment = A operand, Q^T = B operand held in registers)
+//   online softmax in registers: a lane holds 32 of the 64 scores of ONE query, the lane+32 partner the rest
+//   O^T[d][q]  += V^T . P^T    (the S accumulator, converted to bf16, is directly the B operand; V^T comes from an
+//                               LDS image written transposed with the matching key permutation)
+// K/V tiles are prefetched into registers while the previous tile computes (issue-early / write-late).
+#include "aptp_common.h"
+
+namespace {
+
+struct AttnK {
+  const __bf16* q; int64_t qsb, qsl;
+  const __bf16* k; int64_t ksb, ksl;
+  const __bf16* v; int64_t vsb, vsl;
+  __bf16* o; int64_t osb, osl;
+  int B, H, Lq, Lk;
+  float c;   // scale * log2(e)
+};
+
+// position of key offset o (0..15) inside its 16-key group of the V^T image: o = 8a + 4h + c  ->  8h + 4a + c
+__device__ __forceinline__ int vt_pos(int key) {
+  const int o = key & 15;
+  return (key & ~15) | ((o & 4) << 1) | ((o & 8) >> 1) | (o & 3);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * 64];   // [key][d], 16B chunks XOR-swizzled by (key>>1)&7
+  __shared__ __attribute__((aligned(16))) __bf16 Vt[64 * 64];   // [d][vt_pos(key)], chunks XOR-swizzled by (d>>1)&7
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const __bf16* qp = p.q + (int64_t)b * p.qsb + (int64_t)h * 64;
+  const __bf16* kp = p.k + (int64_t)b * p.ksb + (int64_t)h * 64;
+  const __bf16* vp = p.v + (int64_t)b * p.vsb + (int64_t)h * 64;
+
+  // ---- Q^T fragments (B operand: lane (q, hh) element j = Q[q][16s + 8hh + j]) -----------------------------------
+  bf16x8 qf[4];
+  {
+    const int qrow = q0 + lq;
+    const bool ok = qrow < p.Lq;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 t = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) t = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow * p.qsl + 16 * s + 8 * hh);
+      union { uint4 u; bf16x8 v; } cv; cv.u = t;
+      qf[s] = cv.v;
+    }
+  }
+
+  // ---- staging coordinates ------------------------------------------------------------------------------------
+  const int chunk = tid & 7;
+  const int krow = tid >> 3;        // K: rows krow, krow+32
+  const int kpair = tid >> 3;       // V: keys 2*kpair, 2*kpair+1
+  uint4 kreg[2], vreg[2];
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+  auto load_kv = [&](int tile) {
+    const int key0 = tile * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = key0 + krow + 32 * i;
+      kreg[i] = key < p.Lk ? *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ksl + chunk * 8) : zero4;
+      const int vkey = key0 + 2 * kpair + i;
+      vreg[i] = vkey < p.Lk ? *reinterpret_cast<const uint4*>(vp + (int64_t)vkey * p.vsl + chunk * 8) : zero4;
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = krow + 32 * i;
+      const int sw = chunk ^ ((r >> 1) & 7);
+      *reinterpret_cast<uint4*>(Ks + r * 64 + sw * 8) = kreg[i];
+    }
+    // transposed V: dword (V[2kp][d], V[2kp+1][d]) -> Vt[d][vt_pos(2kp) .. +1]
+    union { uint4 u; unsigned short e[8]; } v0, v1;
+    v0.u = vreg[0]; v1.u = vreg[1];
+    const int pos = vt_pos(2 * kpair);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = chunk * 8 + e;
+      const int sw = (pos >> 3) ^ ((d >> 1) & 7);
+      const uint32_t w = (uint32_t)v0.e[e] | ((uint32_t)v1.e[e] << 16);
+      *reinterpret_cast<uint32_t*>(Vt + d * 64 + sw * 8 + (pos & 7)) = w;
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (p.Lk + 63) / 64;
+  load_kv(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();   // everyone finished reading the previous tile
+    store_kv();
+    __syncthreads();
+    if (tile + 1 < ntiles) load_kv(tile + 1);
+
+    // ---- S^T = K . Q^T -------------------------------------------------------------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int r_ = 32 * t + lq;
+        const int sw = (2 * s + hh) ^ ((r_ >> 1) & 7);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + r_ * 64 + sw * 8);
+        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[t], 0, 0, 0);
+      }
+    }
+    // sacc[t][r] = score(key = tile*64 + 32t + (r&3) + 8(r>>2) + 4hh, query = q0 + lq)
+    const int key_base = tile * 64 + 4 * hh;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key_base + 32 * t + (r & 3) + 8 * (r >> 2);
+        const float sv = key < p.Lk ? sacc[t][r] * p.c : -INFINITY;
+        sacc[t][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);       // finite: every tile holds >= 1 valid key
+    const float alpha = exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(sacc[t][r] - m_new);
+        sacc[t][r] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+
+    // ---- O^T += V^T . P^T ----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[t][8 * s2 + j];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d = 32 * u + lq;
+          const int sw = (4 * t + 2 * s2 + hh) ^ ((d >> 1) & 7);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + d * 64 + sw * 8);
+          oacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[u], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------------
+  const int qrow = q0 + lq;
+  if (qrow < p.Lq) {
+    const float inv = 1.0f / l_run;
+    __bf16* op = p.o + (int64_t)b * p.osb + (int64_t)qrow * p.osl + (int64_t)h * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * u + 8 * g + 4 * hh;
+        uint2 w;
+        w.x = pack_bf16x2(oacc[u][4 * g + 0] * inv, oacc[u][4 * g + 1] * inv);
+        w.y = pack_bf16x2(oacc[u][4 * g + 2] * inv, oacc[u][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->q && p->k && p->v && p->o, "attention: null pointer");
+  APTP_CHECK(p->B > 0 && p->heads > 0 && p->Lq > 0 && p->Lk > 0, "attention: bad extents");
+  APTP_CHECK(p->q_stride_l % 8 == 0 && p->k_stride_l % 8 == 0 && p->v_stride_l % 8 == 0 && p->o_stride_l % 4 == 0, "attention: row strides must be multiples of 8 elements");
+  APTP_CHECK(p->q_stride_b % 8 == 0 && p->k_stride_b % 8 == 0 && p->v_stride_b % 8 == 0 && p->o_stride_b % 4 == 0, "attention: batch strides must be multiples of 8 elements");
+  APTP_CHECK(((uintptr_t)p->q % 16) == 0 && ((uintptr_t)p->k % 16) == 0 && ((uintptr_t)p->v % 16) == 0 && ((uintptr_t)p->o % 8) == 0, "attention: pointer alignment");
+  APTP_CHECK(p->q_stride_l >= (int64_t)p->heads * 64 && p->k_stride_l >= (int64_t)p->heads * 64 && p->v_stride_l >= (int64_t)p->heads * 64 && p->o_stride_l >= (int64_t)p->heads * 64, "attention: row stride < heads*64");
+  APTP_CHECK(p->heads <= 65535 && p->B <= 65535, "attention: grid limits");
+  AttnK k;
+  k.q = (const __bf16*)p->q; k.qsb = p->q_stride_b; k.qsl = p->q_stride_l;
+  k.k = (const __bf16*)p->k; k.ksb = p->k_stride_b; k.ksl = p->k_stride_l;
+  k.v = (const __bf16*)p->v; k.vsb = p->v_stride_b; k.vsl = p->v_stride_l;
+  k.o = (__bf16*)p->o; k.osb = p->o_stride_b; k.osl = p->o_stride_l;
+  k.B = p->B; k.H = p->heads; k.Lq = p->Lq; k.Lk = p->Lk;
+  k.c = p->scale * 1.44269504088896340736f;
+  dim3 grid((p->Lq + 127) / 128, p->heads, p->B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}

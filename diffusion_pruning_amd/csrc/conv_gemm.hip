@@ -1,0 +1,459 @@
+// Implicit-GEMM convolution / linear on MFMA (gfx950), channels-last bf16, fp32 accumulate.
+//
+// One kernel family serves every contraction of the masked U-Net: 3x3 / 1x1 convs (stride 1/2, nearest-x2
+// upsample folded into the gather), and all linear layers (1x1 "conv" over tokens).  GEMM view:
+//   M = B*Hout*Wout (pixels / tokens),  N = output channels,  K = taps * Cin_pad.
+// Tile: BM x BN x 64 per 256-thread workgroup (4 waves), double-buffered LDS with an XOR-swizzled
+// [row][64] bf16 image (conflict-free ds_read_b128 for the 16x16x32 MFMA fragments), register-staged
+// global->LDS prefetch one K-step ahead (loads issued before the MFMA phase, written after it).
+// The MFMA is issued with the WEIGHT fragment as the A operand and the activation fragment as the B operand, so
+// each lane ends up with 4 consecutive output channels of one pixel => 8-byte epilogue loads/stores.
+// The architecture-code gate, time-embedding bias, GEGLU, GroupNorm-beta correction, residual and depth lerp are
+// fused into the epilogue (see include/aptp_hip.h for the reference call sites each one replaces).
+#include "aptp_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct KParams {
+  const __bf16* x; int64_t ldx;
+  int B, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, ups;
+  int HinE, WinE;           // effective (upsampled) input extent
+  const __bf16* w; int N; int ncc; int nK; int64_t Ktot;   // ncc = cin_pad/64, nK = taps*ncc
+  const float* bias; const float* rowbias; int ld_rowbias;
+  const float* colgate; int gate_group, gate_B;
+  int act;
+  const float* corr; int corr_B;
+  const __bf16* residual; int64_t ldres;
+  const float* depth; int depth_B; const __bf16* depth_in; int64_t lddin;
+  void* y; int64_t ldy; int out_f32;
+  int split_k; float* ws;
+  int x_bytes, w_bytes;     // buffer-resource extents (bytes)
+  int M, HW, Nout;          // Nout = logical output columns (N/2 for GEGLU)
+  int64_t ws_ld;            // workspace row stride (floats)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// epilogue for 4 consecutive (packed) columns of one output row.  Shared by the GEMM kernel and the split-K reducer.
+// For GEGLU `h` are the value columns at packed col n, `g` the gate columns at packed col n+16, and the logical
+// output column is (n/32)*16 + n%16.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool GEGLU>
+__device__ __forceinline__ void epilogue_quad(const KParams& p, int m, int b, int cls, int n, float h[4], float g[4]) {
+  float v[4];
+  if (p.bias) {
+    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+    h[0] += bb.x; h[1] += bb.y; h[2] += bb.z; h[3] += bb.w;
+    if (GEGLU) {
+      const float4 bg = *reinterpret_cast<const float4*>(p.bias + n + 16);
+      g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+    }
+  }
+  if (p.rowbias) {
+    const float4 rb = *reinterpret_cast<const float4*>(p.rowbias + (int64_t)b * p.ld_rowbias + n);
+    h[0] += rb.x; h[1] += rb.y; h[2] += rb.z; h[3] += rb.w;
+  }
+  const int c = GEGLU ? ((n >> 5) * 16 + (n & 15)) : n;   // logical output column of element 0
+  if (p.colgate) {
+    const float* gr = p.colgate + (int64_t)(b % p.gate_B) * ((GEGLU ? p.Nout : p.N) / p.gate_group);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gm = gr[(c + r) / p.gate_group];
+      h[r] *= gm;
+      if (GEGLU) g[r] *= gm;
+    }
+  }
+  if (GEGLU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = h[r] * gelu_erf_f(g[r]);
+  } else if (p.act == APTP_ACT_SILU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = silu_f(h[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = h[r];
+  }
+  if (p.corr) {
+    const float4 cc = *reinterpret_cast<const float4*>(p.corr + ((int64_t)(b % p.corr_B) * 9 + cls) * p.Nout + c);
+    v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w;
+  }
+  if (p.residual) {
+    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldres + c);
+    union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += (float)ru.e[r];
+  }
+  if (p.depth) {
+    const float d = p.depth[b % p.depth_B];
+    const uint2 rr = *reinterpret_cast<const uint2*>(p.depth_in + (int64_t)m * p.lddin + c);
+    union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (1.0f - d) * (float)ru.e[r] + d * v[r];
+  }
+  if (p.out_f32) {
+    float4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.ldy + c) = o;
+  } else {
+    uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p.y) + (int64_t)m * p.ldy + c) = o;
+  }
+}
+
+__device__ __forceinline__ void row_info(const KParams& p, int m, int& b, int& cls) {
+  b = m / p.HW;
+  cls = 4;
+  if (p.corr) {
+    const int rem = m - b * p.HW;
+    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+    const int rc = oy == 0 ? 0 : (oy == p.Hout - 1 ? 2 : 1);
+    const int cc = ox == 0 ? 0 : (ox == p.Wout - 1 ? 2 : 1);
+    cls = rc * 3 + cc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MF = WTM / 16, NF = WTN / 16;
+  constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+  static_assert(BM % 32 == 0 && BN % 32 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * (BM + BN) * BK];
+  __bf16* As = smem;
+  __bf16* Bs = smem + 2 * BM * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kz = blockIdx.y;
+  const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
+  const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+
+  // ---- per-thread staging coordinates -------------------------------------------------------------------------
+  // Operands are fetched with raw buffer loads: an out-of-range offset returns zeros, which implements the conv
+  // zero padding, the M/N/Cin tails and the predicated-off prefetch without any divergent control flow.
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, p.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const int chunk = tid & 7, rowbase = tid >> 3;
+  int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS];
+#pragma unroll
+  for (int i = 0; i < A_PASS; ++i) {
+    const int m = m0 + rowbase + 32 * i;
+    if (m < p.M) {
+      const int b = m / p.HW, rem = m - b * p.HW;
+      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      a_pix0[i] = b * p.Hin * p.Win;
+    } else {
+      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0;   // always out of range => zero rows
+    }
+  }
+  unsigned b_off[B_PASS];
+#pragma unroll
+  for (int i = 0; i < B_PASS; ++i) {
+    const int n = n0 + rowbase + 32 * i;
+    b_off[i] = n < p.N ? (unsigned)(((int64_t)n * p.Ktot + chunk * 8) * 2) : OOB;
+  }
+
+  // K-iteration state of the NEXT tile to load
+  int l_kt = kt_begin;
+  int l_tap = kt_begin / p.ncc;
+  int l_cc = kt_begin - l_tap * p.ncc;
+  int l_ky = l_tap / p.KW;
+  int l_kx = l_tap - l_ky * p.KW;
+
+  u32x4 ra[A_PASS], rb[B_PASS];
+
+  auto load_tile = [&](bool pred) {
+    const int c = l_cc * BK + chunk * 8;
+    const bool c_ok = pred && c < p.Cin;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
+      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE;
+      iy >>= p.ups; ix >>= p.ups;
+      const unsigned off = (unsigned)(((int64_t)(a_pix0[i] + iy * p.Win + ix) * p.ldx + c) * 2);
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ok ? off : OOB, 0, 0);
+    }
+    const unsigned koff = (unsigned)l_kt * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, (b_off[i] == OOB || !pred) ? OOB : b_off[i] + koff, 0, 0);
+    }
+    // advance
+    ++l_kt;
+    if (++l_cc == p.ncc) {
+      l_cc = 0;
+      if (++l_kx == p.KW) { l_kx = 0; ++l_ky; }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const int r = rowbase + 32 * i;
+      const int sw = chunk ^ ((r >> 1) & 7);
+      *reinterpret_cast<u32x4*>(As + (buf * BM + r) * BK + sw * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      const int r = rowbase + 32 * i;
+      const int sw = chunk ^ ((r >> 1) & 7);
+      *reinterpret_cast<u32x4*>(Bs + (buf * BN + r) * BK + sw * 8) = rb[i];
+    }
+  };
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[MF], wf[NF];
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int r = wm * WTM + i * 16 + frow;
+        const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+        af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * BM + r) * BK + sw * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int r = wn * WTN + j * 16 + frow;
+        const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+        wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * BN + r) * BK + sw * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: one barrier per K-step, loads for step t+1 in flight during the MFMAs of step t ----------------
+  // (the prefetch of the step past the end is predicated off and its zero tile is stored but never read, which keeps
+  // the loop body branch-free so the staging registers stay in VGPRs)
+  {
+    load_tile(kt_begin < kt_end);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      load_tile((kt + 1) < kt_end);
+      compute(buf);
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------------------------
+  // acc[i][j][r] = out[m = m0 + wm*WTM + i*16 + (lane&15)][n = n0 + wn*WTN + j*16 + (lane>>4)*4 + r]
+  if (p.split_k > 1) {
+    float* ws = p.ws + (int64_t)kz * p.M * p.ws_ld;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        float4 o; o.x = acc[i][j][0]; o.y = acc[i][j][1]; o.z = acc[i][j][2]; o.w = acc[i][j][3];
+        *reinterpret_cast<float4*>(ws + (int64_t)m * p.ws_ld + n) = o;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    if (m >= p.M) continue;
+    int b, cls;
+    row_info(p, m, b, cls);
+    if (p.act == APTP_ACT_GEGLU) {
+      if constexpr (NF % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NF; j += 2) {
+          const int n = n0 + wn * WTN + j * 16 + fq * 4;
+          if (n >= p.N) continue;
+          float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+          epilogue_quad<true>(p, m, b, cls, n, h, g);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        epilogue_quad<false>(p, m, b, cls, n, h, h);
+      }
+    }
+  }
+}
+
+// split-K reducer + epilogue: one thread per (row, 4 packed columns)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
+  const int quads = (p.act == APTP_ACT_GEGLU) ? p.N / 8 : p.N / 4;   // GEGLU: one thread per h-quad (+ its g-quad)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)p.M * quads) return;
+  const int m = (int)(idx / quads);
+  const int q = (int)(idx - (int64_t)m * quads);
+  int n;
+  if (p.act == APTP_ACT_GEGLU) n = (q >> 2) * 32 + (q & 3) * 4;
+  else n = q * 4;
+  float h[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.split_k; ++z) {
+    const float* row = p.ws + ((int64_t)z * p.M + m) * p.ws_ld;
+    const float4 a = *reinterpret_cast<const float4*>(row + n);
+    h[0] += a.x; h[1] += a.y; h[2] += a.z; h[3] += a.w;
+    if (p.act == APTP_ACT_GEGLU) {
+      const float4 c = *reinterpret_cast<const float4*>(row + n + 16);
+      g[0] += c.x; g[1] += c.y; g[2] += c.z; g[3] += c.w;
+    }
+  }
+  int b, cls;
+  row_info(p, m, b, cls);
+  if (p.act == APTP_ACT_GEGLU) epilogue_quad<true>(p, m, b, cls, n, h, g);
+  else epilogue_quad<false>(p, m, b, cls, n, h, h);
+}
+
+struct TileCfg { int bm, bn; };
+const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64}};
+
+int pick_tile(const AptpConvGemmParams* p, int M) {
+  if (p->tile != APTP_TILE_AUTO) return p->tile;
+  const bool geglu = p->act == APTP_ACT_GEGLU;
+  // N-tile: least padding waste; 160 not usable with GEGLU (needs an even number of 16-col fragments per wave)
+  auto waste = [&](int bn) { return ((p->N + bn - 1) / bn) * bn - p->N; };
+  int bn = 128;
+  if (!geglu && waste(160) < waste(128)) bn = 160;
+  if (p->N <= 64 || (waste(64) < waste(bn) && p->N < 128)) bn = 64;
+  auto blocks = [&](int bm, int bn_) { return (int64_t)((M + bm - 1) / bm) * ((p->N + bn_ - 1) / bn_); };
+  int bm = blocks(128, bn) >= 512 ? 128 : 64;
+  if (bn == 160) return bm == 128 ? APTP_TILE_128x160 : APTP_TILE_64x160;
+  if (bn == 128) return bm == 128 ? APTP_TILE_128x128 : APTP_TILE_64x128;
+  return bm == 128 ? APTP_TILE_128x64 : APTP_TILE_64x64;
+}
+
+int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
+  APTP_CHECK(p && p->x && p->w && p->y, "conv_gemm: null pointer");
+  APTP_CHECK(p->B > 0 && p->Hin > 0 && p->Win > 0 && p->Hout > 0 && p->Wout > 0, "conv_gemm: bad extent");
+  APTP_CHECK(p->Cin > 0 && p->Cin % 8 == 0, "conv_gemm: Cin (%d) must be a positive multiple of 8", p->Cin);
+  APTP_CHECK(p->ldx % 8 == 0 && p->ldx >= p->Cin, "conv_gemm: ldx (%lld) must be a multiple of 8 and >= Cin", (long long)p->ldx);
+  APTP_CHECK(p->N > 0 && p->N % 8 == 0, "conv_gemm: N (%d) must be a positive multiple of 8", p->N);
+  APTP_CHECK(p->cin_pad % BK == 0 && p->cin_pad >= p->Cin && p->cin_pad < p->Cin + BK, "conv_gemm: cin_pad (%d) != ceil(Cin/64)*64", p->cin_pad);
+  APTP_CHECK(p->KH >= 1 && p->KW >= 1 && p->stride >= 1 && p->pad >= 0 && (p->ups == 0 || p->ups == 1), "conv_gemm: bad filter geometry");
+  APTP_CHECK(((uintptr_t)p->x % 16) == 0 && ((uintptr_t)p->w % 16) == 0 && ((uintptr_t)p->y % 8) == 0, "conv_gemm: pointer alignment");
+  const int geglu = p->act == APTP_ACT_GEGLU;
+  APTP_CHECK(!geglu || p->N % 32 == 0, "conv_gemm: GEGLU needs N %% 32 == 0");
+  const int nout = geglu ? p->N / 2 : p->N;
+  APTP_CHECK(p->ldy >= nout && p->ldy % 4 == 0, "conv_gemm: ldy (%lld) must be >= %d and a multiple of 4", (long long)p->ldy, nout);
+  APTP_CHECK(!p->colgate || (p->gate_group > 0 && p->gate_B > 0 && nout % p->gate_group == 0), "conv_gemm: bad gate geometry");
+  APTP_CHECK(!p->corr || (p->corr_B > 0 && p->Hout >= 2 && p->Wout >= 2), "conv_gemm: corr needs Hout,Wout >= 2");
+  APTP_CHECK(!p->residual || (p->ldres % 4 == 0 && ((uintptr_t)p->residual % 8) == 0), "conv_gemm: residual alignment");
+  APTP_CHECK(!p->depth || (p->depth_in && p->depth_B > 0 && p->lddin % 4 == 0), "conv_gemm: depth gate needs depth_in");
+  APTP_CHECK(!p->rowbias || p->ld_rowbias % 4 == 0, "conv_gemm: ld_rowbias must be a multiple of 4");
+  APTP_CHECK(p->split_k >= 1, "conv_gemm: split_k >= 1");
+  const int64_t M64 = (int64_t)p->B * p->Hout * p->Wout;
+  APTP_CHECK(M64 < (1ll << 31), "conv_gemm: M too large");
+  // geometry consistency: every output pixel's centre tap must map inside the (upsampled) input
+  const int HinE = p->Hin << p->ups, WinE = p->Win << p->ups;
+  APTP_CHECK(p->Hout == (HinE + 2 * p->pad - p->KH) / p->stride + 1 && p->Wout == (WinE + 2 * p->pad - p->KW) / p->stride + 1,
+             "conv_gemm: Hout/Wout inconsistent with input extent, filter, stride and padding");
+  k.x = (const __bf16*)p->x; k.ldx = p->ldx;
+  k.B = p->B; k.Hin = p->Hin; k.Win = p->Win; k.Cin = p->Cin; k.Hout = p->Hout; k.Wout = p->Wout;
+  k.KH = p->KH; k.KW = p->KW; k.stride = p->stride; k.pad = p->pad; k.ups = p->ups;
+  k.HinE = HinE; k.WinE = WinE;
+  k.w = (const __bf16*)p->w; k.N = p->N; k.ncc = p->cin_pad / BK; k.nK = p->KH * p->KW * k.ncc;
+  k.Ktot = (int64_t)k.nK * BK;
+  k.bias = p->bias; k.rowbias = p->rowbias; k.ld_rowbias = p->ld_rowbias;
+  k.colgate = p->colgate; k.gate_group = p->gate_group; k.gate_B = p->gate_B;
+  k.act = p->act; k.corr = p->corr; k.corr_B = p->corr_B;
+  k.residual = (const __bf16*)p->residual; k.ldres = p->ldres;
+  k.depth = p->depth; k.depth_B = p->depth_B; k.depth_in = (const __bf16*)p->depth_in; k.lddin = p->lddin;
+  k.y = p->y; k.ldy = p->ldy; k.out_f32 = p->out_f32;
+  k.split_k = p->split_k < k.nK ? p->split_k : k.nK;
+  k.ws = (float*)p->workspace;
+  k.M = (int)M64; k.HW = p->Hout * p->Wout; k.Nout = nout;
+  k.ws_ld = p->N;
+  const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * 2;
+  const int64_t wb = (int64_t)p->N * k.Ktot * 2;
+  APTP_CHECK(xb < (1ll << 31) && wb < (1ll << 31), "conv_gemm: operand larger than 2 GiB");
+  k.x_bytes = (int)xb; k.w_bytes = (int)wb;
+  return APTP_OK;
+}
+
+template <int BM, int BN>
+void launch_tile(const KParams& k, hipStream_t s) {
+  const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
+  dim3 grid(tiles, k.split_k, 1);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
+}
+
+}  // namespace
+
+extern "C" int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p) {
+  if (!p || p->split_k <= 1) return 0;
+  return (int64_t)p->split_k * p->B * p->Hout * p->Wout * p->N * (int64_t)sizeof(float);
+}
+
+extern "C" int aptp_conv_gemm_suggest_split_k(const AptpConvGemmParams* p) {
+  if (!p) return 1;
+  const int M = p->B * p->Hout * p->Wout;
+  const int t = pick_tile(p, M);
+  const int64_t blocks = (int64_t)((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((p->N + kTiles[t].bn - 1) / kTiles[t].bn);
+  const int nK = p->KH * p->KW * (p->cin_pad / BK);
+  if (blocks >= 256) return 1;
+  int s = (int)((512 + blocks - 1) / blocks);
+  const int max_s = nK / 8 > 0 ? nK / 8 : 1;   // keep >= 8 K-steps per slice
+  if (s > max_s) s = max_s;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream) {
+  KParams k;
+  const int rc = fill_kparams(p, k);
+  if (rc != APTP_OK) return rc;
+  if (k.split_k > 1) APTP_CHECK(k.ws != nullptr && ((uintptr_t)k.ws % 16) == 0, "conv_gemm: split_k > 1 needs a 16B-aligned workspace");
+  hipStream_t s = (hipStream_t)stream;
+  int t = pick_tile(p, k.M);
+  if (k.act == APTP_ACT_GEGLU && (t == APTP_TILE_128x160 || t == APTP_TILE_64x160)) {
+    aptp_set_error("conv_gemm: GEGLU cannot use a 160-wide tile");
+    return APTP_EINVAL;
+  }
+  switch (t) {
+    case APTP_TILE_128x128: launch_tile<128, 128>(k, s); break;
+    case APTP_TILE_128x160: launch_tile<128, 160>(k, s); break;
+    case APTP_TILE_64x128: launch_tile<64, 128>(k, s); break;
+    case APTP_TILE_64x160: launch_tile<64, 160>(k, s); break;
+    case APTP_TILE_128x64: launch_tile<128, 64>(k, s); break;
+    case APTP_TILE_64x64: launch_tile<64, 64>(k, s); break;
+    default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
+  }
+  APTP_LAUNCH_CHECK();
+  if (k.split_k > 1) {
+    const int quads = (k.act == APTP_ACT_GEGLU) ? k.N / 8 : k.N / 4;
+    const int64_t total = (int64_t)k.M * quads;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
+    APTP_LAUNCH_CHECK();
+  }
+  return APTP_OK;
+}

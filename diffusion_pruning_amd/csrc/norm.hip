@@ -1,0 +1,279 @@
+// GroupNorm(+SiLU) and LayerNorm over channels-last bf16 (gfx950).  HBM-bound: 16-byte vector loads/stores,
+// fp32 statistics, deterministic two-stage reduction (no float atomics).
+#include "aptp_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// GroupNorm
+//   stage 1 (gn_stats): grid (nchunk, B); each workgroup reduces a slab of rows to per-group (sum, sumsq)
+//   stage 2 (gn_apply): grid (nchunk2, B); folds the nchunk partials, then y = act(x*scale + shift)
+// Thread -> channel-octet mapping is fixed for the whole kernel (octet o = tid % TPR (+ 256*page)), so the
+// per-channel accumulators / affine coefficients live in registers.
+// ------------------------------------------------------------------------------------------------------------
+struct GnK {
+  const __bf16* x; int64_t ldx; __bf16* y; int64_t ldy;
+  int B, HW, C, G, cg, CO;   // CO = ceil(C/8) octets per row
+  const float* gamma; const float* beta; float eps; int silu;
+  float* ws; int nchunk;
+  int TPR, RPAR;             // threads per row (= min(CO,256)), rows processed in parallel (256/TPR)
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
+  __shared__ float red[2][2048 * NP];   // [sum|sumsq][RPAR * TPR*8*NP]  (RPAR*TPR <= 256)
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = (int)(((int64_t)p.HW * chunk) / p.nchunk), r1 = (int)(((int64_t)p.HW * (chunk + 1)) / p.nchunk);
+  const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
+  const bool active = rl < p.RPAR;
+  float s[NP][8], ss[NP][8];
+#pragma unroll
+  for (int pg = 0; pg < NP; ++pg)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[pg][e] = 0.f; ss[pg][e] = 0.f; }
+  if (active) {
+    const __bf16* base = p.x + ((int64_t)b * p.HW) * p.ldx;
+    for (int r = r0 + rl; r < r1; r += p.RPAR) {
+#pragma unroll
+      for (int pg = 0; pg < NP; ++pg) {
+        const int o = ot + pg * 256;
+        if (o < p.CO) {
+          const uint4 q = *reinterpret_cast<const uint4*>(base + (int64_t)r * p.ldx + o * 8);
+          float f[8];
+          unpack_bf16x8(q, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[pg][e] += f[e]; ss[pg][e] += f[e] * f[e]; }
+        }
+      }
+    }
+  }
+  // per-channel partials -> LDS [rl][channel]
+  const int CP = p.TPR * 8 * NP;   // padded channel count in LDS rows
+  if (active) {
+#pragma unroll
+    for (int pg = 0; pg < NP; ++pg) {
+      const int o = ot + pg * 256;
+      if (o < p.CO) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[0][rl * CP + o * 8 + e] = s[pg][e];
+          red[1][rl * CP + o * 8 + e] = ss[pg][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // 8 threads per group fold channels x RPAR
+  const int g = tid >> 3, sub = tid & 7;
+  float a = 0.f, a2 = 0.f;
+  if (g < p.G) {
+    const int n = p.cg * p.RPAR;
+    for (int i = sub; i < n; i += 8) {
+      const int rr = i / p.cg, c = g * p.cg + (i - rr * p.cg);
+      a += red[0][rr * CP + c];
+      a2 += red[1][rr * CP + c];
+    }
+  }
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off);
+    a2 += __shfl_xor(a2, off);
+  }
+  if (g < p.G && sub == 0) {
+    float* o = p.ws + (((int64_t)b * p.nchunk + chunk) * p.G + g) * 2;
+    o[0] = a;
+    o[1] = a2;
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
+  __shared__ float mean_s[32], rstd_s[32];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  if (tid < p.G) {
+    float a = 0.f, a2 = 0.f;
+    const float* w = p.ws + ((int64_t)b * p.nchunk * p.G + tid) * 2;
+    for (int c = 0; c < p.nchunk; ++c) { a += w[(int64_t)c * p.G * 2]; a2 += w[(int64_t)c * p.G * 2 + 1]; }
+    const float inv = 1.0f / ((float)p.cg * (float)p.HW);
+    const float mean = a * inv;
+    float var = a2 * inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    mean_s[tid] = mean;
+    rstd_s[tid] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
+  if (rl >= p.RPAR) return;
+  float sc[NP][8], sh[NP][8];
+  unsigned valid[NP];
+#pragma unroll
+  for (int pg = 0; pg < NP; ++pg) {
+    const int o = ot + pg * 256;
+    valid[pg] = 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = o * 8 + e;
+      if (o < p.CO && c < p.C) {
+        const int g = c / p.cg;
+        const float k = rstd_s[g] * p.gamma[c];
+        sc[pg][e] = k;
+        sh[pg][e] = p.beta[c] - mean_s[g] * k;
+        valid[pg] |= 1u << e;
+      } else {
+        sc[pg][e] = 0.f; sh[pg][e] = 0.f;
+      }
+    }
+  }
+  const int r0 = (int)(((int64_t)p.HW * chunk) / gridDim.x), r1 = (int)(((int64_t)p.HW * (chunk + 1)) / gridDim.x);
+  const __bf16* xb = p.x + ((int64_t)b * p.HW) * p.ldx;
+  __bf16* yb = p.y + ((int64_t)b * p.HW) * p.ldy;
+  for (int r = r0 + rl; r < r1; r += p.RPAR) {
+#pragma unroll
+    for (int pg = 0; pg < NP; ++pg) {
+      const int o = ot + pg * 256;
+      if (o < p.CO) {
+        const uint4 q = *reinterpret_cast<const uint4*>(xb + (int64_t)r * p.ldx + o * 8);
+        float f[8];
+        unpack_bf16x8(q, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = f[e] * sc[pg][e] + sh[pg][e];
+          if (p.silu) v = silu_f(v);
+          // channels >= C inside the last octet are padding: always written as exact zero
+          f[e] = ((valid[pg] >> e) & 1u) ? v : 0.f;
+        }
+        *reinterpret_cast<uint4*>(yb + (int64_t)r * p.ldy + o * 8) = pack_bf16x8(f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, lane handles octets lane, lane+64, ...; exact two-pass statistics in registers.
+// ------------------------------------------------------------------------------------------------------------
+struct LnK {
+  const __bf16* x; int64_t ldx; __bf16* y; int64_t ldy; int rows, C, CO;
+  const float* gamma; const float* beta; float eps;
+};
+
+template <int NO>
+__global__ __launch_bounds__(256) void ln_kernel(const LnK p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= p.rows) return;
+  float f[NO][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NO; ++i) {
+    const int o = lane + 64 * i;
+    if (o < p.CO) {
+      const uint4 q = *reinterpret_cast<const uint4*>(p.x + (int64_t)row * p.ldx + o * 8);
+      unpack_bf16x8(q, f[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += f[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[i][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  const float mean = sum / (float)p.C;
+  float vs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NO; ++i) {
+    const int o = lane + 64 * i;
+    if (o < p.CO) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; vs += d * d; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) vs += __shfl_xor(vs, off);
+  const float rstd = rsqrtf(vs / (float)p.C + p.eps);
+#pragma unroll
+  for (int i = 0; i < NO; ++i) {
+    const int o = lane + 64 * i;
+    if (o < p.CO) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + o * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.gamma + o * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.beta + o * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.beta + o * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = (f[i][e] - mean) * rstd * gg[e] + bb[e];
+      *reinterpret_cast<uint4*>(p.y + (int64_t)row * p.ldy + o * 8) = pack_bf16x8(o8);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int aptp_groupnorm_nchunk(int HW) {
+  int n = HW / 64;
+  if (n < 1) n = 1;
+  if (n > 32) n = 32;
+  return n;
+}
+
+extern "C" int64_t aptp_groupnorm_workspace_bytes(const AptpGroupNormParams* p) {
+  if (!p) return 0;
+  return (int64_t)p->B * aptp_groupnorm_nchunk(p->HW) * p->groups * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->x && p->y && p->gamma && p->beta && p->workspace, "groupnorm: null pointer");
+  APTP_CHECK(p->B > 0 && p->HW > 0 && p->C > 0 && p->groups > 0 && p->groups <= 32, "groupnorm: bad extents (groups <= 32)");
+  APTP_CHECK(p->C % p->groups == 0, "groupnorm: C (%d) not divisible by groups (%d)", p->C, p->groups);
+  const int CO = (p->C + 7) / 8;
+  APTP_CHECK(p->ldx % 8 == 0 && p->ldy % 8 == 0 && p->ldx >= CO * 8 && p->ldy >= CO * 8, "groupnorm: ld must be a multiple of 8 and >= roundup8(C)");
+  APTP_CHECK(((uintptr_t)p->x % 16) == 0 && ((uintptr_t)p->y % 16) == 0, "groupnorm: pointer alignment");
+  APTP_CHECK(CO <= 512, "groupnorm: C too large (max 4096)");
+  GnK k;
+  k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.y = (__bf16*)p->y; k.ldy = p->ldy;
+  k.B = p->B; k.HW = p->HW; k.C = p->C; k.G = p->groups; k.cg = p->C / p->groups; k.CO = CO;
+  k.gamma = p->gamma; k.beta = p->beta; k.eps = p->eps; k.silu = p->silu;
+  k.ws = (float*)p->workspace; k.nchunk = aptp_groupnorm_nchunk(p->HW);
+  k.TPR = CO < 256 ? CO : 256;
+  k.RPAR = 256 / k.TPR;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid1(k.nchunk, p->B);
+  int nchunk2 = p->HW / 16;   // ~16+ rows per apply block
+  if (nchunk2 < 1) nchunk2 = 1;
+  if (nchunk2 > 256) nchunk2 = 256;
+  dim3 grid2(nchunk2, p->B);
+  if (CO <= 256) {
+    hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);
+    hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(256), 0, s, k);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<2>, grid1, dim3(256), 0, s, k);
+    hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(256), 0, s, k);
+  }
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}
+
+extern "C" int aptp_layernorm(const AptpLayerNormParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
+  APTP_CHECK(p->rows > 0 && p->C > 0 && p->C % 8 == 0 && p->C <= 2048, "layernorm: C (%d) must be a multiple of 8, <= 2048", p->C);
+  APTP_CHECK(p->ldx % 8 == 0 && p->ldy % 8 == 0 && p->ldx >= p->C && p->ldy >= p->C, "layernorm: ld");
+  APTP_CHECK(((uintptr_t)p->x % 16) == 0 && ((uintptr_t)p->y % 16) == 0 && ((uintptr_t)p->gamma % 16) == 0 && ((uintptr_t)p->beta % 16) == 0, "layernorm: pointer alignment");
+  LnK k;
+  k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.y = (__bf16*)p->y; k.ldy = p->ldy;
+  k.rows = p->rows; k.C = p->C; k.CO = p->C / 8; k.gamma = p->gamma; k.beta = p->beta; k.eps = p->eps;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((p->rows + 3) / 4);
+  const int no = (k.CO + 63) / 64;
+  switch (no) {
+    case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, dim3(256), 0, s, k); break;
+    case 2: hipLaunchKernelGGL(ln_kernel<2>, grid, dim3(256), 0, s, k); break;
+    case 3: hipLaunchKernelGGL(ln_kernel<3>, grid, dim3(256), 0, s, k); break;
+    default: hipLaunchKernelGGL(ln_kernel<4>, grid, dim3(256), 0, s, k); break;
+  }
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}

@@ -1,0 +1,291 @@
+"""Tensor-level wrappers over the C ABI (include/aptp_hip.h).
+
+Activations are bf16 channels-last tensors ``[B, H, W, C]`` whose last dim is contiguous; the pixel stride
+``x.stride(2)`` may exceed C (a channel slice of a wider buffer), which is how skip-concats are consumed without
+copies.  Token tensors ``[B, L, C]`` are passed as ``[B, L, 1, C]``.  All launches go to torch's current stream,
+so the whole forward can be captured into a HIP graph with ``torch.cuda.graph``.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionParams, ConvGemmParams, GroupNormParams, LayerNormParams
+
+BK = 64
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _check_act(x: torch.Tensor, name: str):
+    if x.dtype != torch.bfloat16 or x.dim() != 4 or x.stride(3) != 1 or not x.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA bf16 [B,H,W,C] tensor with contiguous channels, got "
+                         f"{x.dtype} {tuple(x.shape)} strides {x.stride()}")
+    B, H, W, C = x.shape
+    ld = _ld(x)
+    if (W > 1 and x.stride(2) != ld) or (H > 1 and x.stride(1) != W * ld) or (B > 1 and x.stride(0) != H * W * ld):
+        raise ValueError(f"{name}: rows must be uniformly strided (ld={ld}), got strides {x.stride()}")
+    if ld % 8 != 0 or x.data_ptr() % 16 != 0:
+        raise ValueError(f"{name}: pixel stride {ld} must be a multiple of 8 elements and the base 16-byte aligned")
+    return ld
+
+
+def _ld(x: torch.Tensor) -> int:
+    # pixel stride of a [B,H,W,C] view (robust to size-1 dims)
+    B, H, W, C = x.shape
+    if W > 1:
+        return x.stride(2)
+    if H > 1:
+        return x.stride(1)
+    if B > 1:
+        return x.stride(0)
+    return max(x.stride(2), C)
+
+
+@dataclass
+class PackedWeight:
+    """bf16 weights in the kernel's [N][taps][cin_pad] layout + fp32 bias (both already gathered/compacted)."""
+    w: torch.Tensor            # bf16 [N, KH*KW, cin_pad]
+    bias: Optional[torch.Tensor]  # fp32 [N] or None
+    N: int
+    Cin: int
+    KH: int
+    KW: int
+    geglu: bool = False
+
+    @property
+    def cin_pad(self) -> int:
+        return self.w.shape[2]
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out_idx: Optional[torch.Tensor] = None,
+                in_idx: Optional[torch.Tensor] = None, n_pad_to: int = 8, cin_pad_to: int = 8,
+                geglu: bool = False, device=None) -> PackedWeight:
+    """Pack an OIHW conv weight (or [out,in] linear weight) for aptp_conv_gemm.
+
+    out_idx / in_idx: live output / input channel indices (architecture-code compaction; the reference's
+    prune() slicing, blocks.py:436-463, 159-177, 55-64, 126).  Output rows and input columns are zero-padded to
+    multiples of n_pad_to / cin_pad_to (pad rows produce exact zeros), then Cin to a multiple of 64.
+    geglu: interleave the two halves of a GEGLU projection in [16 value | 16 gate] row blocks so the epilogue finds
+    h and g of one hidden unit in the same lane."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    device = device or w.device
+    w = w.to(device=device, dtype=torch.float32)
+    if bias is not None:
+        bias = bias.to(device=device, dtype=torch.float32)
+    if geglu:
+        inner = w.shape[0] // 2
+        wh, wg = w[:inner], w[inner:]
+        bh, bg = (bias[:inner], bias[inner:]) if bias is not None else (None, None)
+        if out_idx is not None:
+            out_idx = out_idx.to(device)
+            wh, wg = wh[out_idx], wg[out_idx]
+            if bias is not None:
+                bh, bg = bh[out_idx], bg[out_idx]
+        if in_idx is not None:
+            in_idx = in_idx.to(device)
+            wh, wg = wh[:, in_idx], wg[:, in_idx]
+        n_live = wh.shape[0]
+        n_p = round_up(n_live, 16)
+
+        def padrows(t):
+            if t.shape[0] == n_p:
+                return t
+            return torch.cat([t, t.new_zeros((n_p - t.shape[0],) + tuple(t.shape[1:]))], 0)
+        wh, wg = padrows(wh), padrows(wg)
+        # [n_p/16, 16, ...] blocks interleaved
+        w = torch.stack([wh.reshape(n_p // 16, 16, *wh.shape[1:]), wg.reshape(n_p // 16, 16, *wg.shape[1:])], 1)
+        w = w.reshape(2 * n_p, *wh.shape[1:])
+        if bias is not None:
+            bh, bg = padrows(bh), padrows(bg)
+            bias = torch.stack([bh.reshape(n_p // 16, 16), bg.reshape(n_p // 16, 16)], 1).reshape(2 * n_p)
+    else:
+        if out_idx is not None:
+            out_idx = out_idx.to(device)
+            w = w[out_idx]
+            if bias is not None:
+                bias = bias[out_idx]
+        if in_idx is not None:
+            w = w[:, in_idx.to(device)]
+        n_live = w.shape[0]
+        n_p = round_up(n_live, n_pad_to)
+        if n_p != n_live:
+            w = torch.cat([w, w.new_zeros((n_p - n_live,) + tuple(w.shape[1:]))], 0)
+            if bias is not None:
+                bias = torch.cat([bias, bias.new_zeros(n_p - n_live)], 0)
+    N, Cin, KH, KW = w.shape
+    cin_live = round_up(Cin, cin_pad_to)
+    cin_pad = round_up(cin_live, BK)
+    packed = torch.zeros(N, KH * KW, cin_pad, dtype=torch.bfloat16, device=device)
+    packed[:, :, :Cin] = w.permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(torch.bfloat16)
+    return PackedWeight(packed.contiguous(), None if bias is None else bias.contiguous(), N, cin_live, KH, KW, geglu)
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (stream-ordered reuse: kernels on one stream serialise)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.is_current_stream_capturing())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None, ups: int = 0,
+              out: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+              colgate: Optional[torch.Tensor] = None, gate_group: int = 0, act: int = ACT_NONE,
+              corr: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+              depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
+              out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0) -> torch.Tensor:
+    """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites."""
+    lib = _lib.load()
+    _check_act(x, "conv_gemm x")
+    B, Hin, Win, Cx = x.shape
+    if Cx != pw.Cin:
+        raise ValueError(f"conv_gemm: x has {Cx} channels, packed weight expects {pw.Cin}")
+    if pad is None:
+        pad = pw.KH // 2
+    HinE, WinE = Hin << ups, Win << ups
+    Hout = (HinE + 2 * pad - pw.KH) // stride + 1
+    Wout = (WinE + 2 * pad - pw.KW) // stride + 1
+    if pw.geglu:
+        act = ACT_GEGLU
+    nout = pw.N // 2 if act == ACT_GEGLU else pw.N
+    if out is None:
+        out = torch.empty(B, Hout, Wout, nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    else:
+        if tuple(out.shape) != (B, Hout, Wout, nout) or out.stride(3) != 1:
+            raise ValueError(f"conv_gemm: out shape {tuple(out.shape)} != {(B, Hout, Wout, nout)}")
+        if out.dtype != (torch.float32 if out_f32 else torch.bfloat16):
+            raise ValueError("conv_gemm: out dtype mismatch")
+    p = ConvGemmParams()
+    p.x, p.ldx = x.data_ptr(), _ld(x)
+    p.B, p.Hin, p.Win, p.Cin, p.Hout, p.Wout = B, Hin, Win, Cx, Hout, Wout
+    p.KH, p.KW, p.stride, p.pad, p.ups = pw.KH, pw.KW, stride, pad, ups
+    p.w, p.N, p.cin_pad = pw.w.data_ptr(), pw.N, pw.cin_pad
+    p.bias = None if pw.bias is None else pw.bias.data_ptr()
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.dim() == 2 and rowbias.shape[0] == B and rowbias.stride(1) == 1
+        assert rowbias.shape[1] >= pw.N
+        p.rowbias, p.ld_rowbias = rowbias.data_ptr(), rowbias.stride(0)
+    if colgate is not None:
+        assert colgate.dtype == torch.float32 and colgate.dim() == 2 and colgate.is_contiguous()
+        assert gate_group > 0 and colgate.shape[1] * gate_group == nout and B % colgate.shape[0] == 0
+        p.colgate, p.gate_group, p.gate_B = colgate.data_ptr(), gate_group, colgate.shape[0]
+    p.act = act
+    if corr is not None:
+        assert corr.dtype == torch.float32 and corr.is_contiguous() and corr.shape[1:] == (9, nout)
+        assert B % corr.shape[0] == 0
+        p.corr, p.corr_B = corr.data_ptr(), corr.shape[0]
+    if residual is not None:
+        _check_act(residual, "conv_gemm residual")
+        assert tuple(residual.shape) == (B, Hout, Wout, nout)
+        p.residual, p.ldres = residual.data_ptr(), _ld(residual)
+    if depth is not None:
+        assert depth.dtype == torch.float32 and depth.dim() == 1 and B % depth.shape[0] == 0 and depth_in is not None
+        _check_act(depth_in, "conv_gemm depth_in")
+        assert tuple(depth_in.shape) == (B, Hout, Wout, nout)
+        p.depth, p.depth_B = depth.data_ptr(), depth.shape[0]
+        p.depth_in, p.lddin = depth_in.data_ptr(), _ld(depth_in)
+    p.y, p.ldy, p.out_f32 = out.data_ptr(), _ld(out), int(out_f32)
+    p.tile = tile
+    p.split_k = 1
+    if split_k is None:
+        split_k = lib.aptp_conv_gemm_suggest_split_k(ctypes.byref(p))
+    p.split_k = max(1, int(split_k))
+    ws = None
+    if p.split_k > 1:
+        ws = _workspace(lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(p)), x.device)
+        p.workspace = ws.data_ptr()
+    _lib.check(lib.aptp_conv_gemm(ctypes.byref(p), _stream()), "aptp_conv_gemm")
+    return out
+
+
+def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
+    """x [B, L, C] -> [B, L, N] through the 1x1 path (tokens = H, W = 1)."""
+    B, L, C = x.shape
+    out = kw.pop("out", None)
+    for k in ("residual", "depth_in"):
+        if kw.get(k) is not None:
+            kw[k] = kw[k].unsqueeze(2)
+    y = conv_gemm(x.unsqueeze(2), pw, pad=0, out=None if out is None else out.unsqueeze(2), **kw)
+    return y.squeeze(2)
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+              C: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm(+SiLU) of a [B,H,W,Cp] tensor over its first C real channels (Cp = roundup8(C))."""
+    lib = _lib.load()
+    _check_act(x, "groupnorm x")
+    B, H, W, Cp = x.shape
+    C = Cp if C is None else C
+    assert Cp == round_up(C, 8), f"groupnorm: tensor width {Cp} != roundup8({C})"
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+    if out is None:
+        out = torch.empty(B, H, W, Cp, dtype=torch.bfloat16, device=x.device)
+    p = GroupNormParams()
+    p.x, p.ldx, p.y, p.ldy = x.data_ptr(), _ld(x), out.data_ptr(), _ld(out)
+    p.B, p.HW, p.C, p.groups = B, H * W, C, groups
+    p.gamma, p.beta, p.eps, p.silu = gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
+    ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
+    p.workspace = ws.data_ptr()
+    _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm over the last dim of a bf16 [B, L, C] tensor."""
+    lib = _lib.load()
+    B, L, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.stride(2) == 1 and x.is_cuda
+    ld = x.stride(1) if L > 1 else max(x.stride(1), C)
+    assert B == 1 or L == 1 or x.stride(0) == L * ld
+    if out is None:
+        out = torch.empty(B, L, C, dtype=torch.bfloat16, device=x.device)
+    p = LayerNormParams()
+    p.x, p.ldx, p.y, p.ldy = x.data_ptr(), ld, out.data_ptr(), out.stride(1) if L > 1 else C
+    p.rows, p.C = B * L, C
+    p.gamma, p.beta, p.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    _lib.check(lib.aptp_layernorm(ctypes.byref(p), _stream()), "aptp_layernorm")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v with head_dim 64.  q [B, Lq, >=heads*64], k/v [B, Lk, >=heads*64] are bf16 views
+    (e.g. column slices of a fused QKV buffer); heads are laid out as consecutive 64-wide column blocks."""
+    lib = _lib.load()
+    B, Lq = q.shape[0], q.shape[1]
+    Lk = k.shape[1]
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1 and t.shape[2] == heads * 64 and t.is_cuda
+    if out is None:
+        out = torch.empty(B, Lq, heads * 64, dtype=torch.bfloat16, device=q.device)
+    p = AttentionParams()
+    p.q, p.q_stride_b, p.q_stride_l = q.data_ptr(), q.stride(0), q.stride(1)
+    p.k, p.k_stride_b, p.k_stride_l = k.data_ptr(), k.stride(0), k.stride(1)
+    p.v, p.v_stride_b, p.v_stride_l = v.data_ptr(), v.stride(0), v.stride(1)
+    p.o, p.o_stride_b, p.o_stride_l = out.data_ptr(), out.stride(0), out.stride(1)
+    p.B, p.heads, p.Lq, p.Lk = B, heads, Lq, Lk
+    p.scale = (1.0 / 8.0) if scale is None else scale
+    _lib.check(lib.aptp_attention(ctypes.byref(p), _stream()), "aptp_attention")
+    return out

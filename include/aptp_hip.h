@@ -1,0 +1,155 @@
+/*
+ * aptp_hip.h — C ABI of libaptp_hip.so: the MI355X (gfx950) kernels behind APTP's masked-U-Net denoising path.
+ *
+ * The reference (rezashkv/diffusion_pruning) is pure Python and has no FFI boundary of its own; every entry point
+ * below replaces a *call site into torch/diffusers* inside the reference's gated blocks.  Citations are
+ * file:line relative to the reference tree.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (PyTorch allocates everything, including workspaces).
+ *   - Activations are bf16, channels-last: a conv input is [B, H, W, C] with a row (pixel) stride `ld*` in
+ *     ELEMENTS, so strided channel-slices of wider buffers can be read/written in place (no torch.cat copies).
+ *     A linear layer is the KH=KW=1 case with H = tokens per sample, W = 1.
+ *   - Weights are pre-packed bf16 [N][KH*KW][Cin_pad] (K-contiguous), Cin_pad = ceil(Cin/64)*64, zero padded.
+ *   - Epilogue vectors (bias, gates, corrections, depth) are fp32.
+ *   - Every launch is asynchronous on `stream`; no hidden sync, no global state => hipGraph-capturable.
+ *   - Return 0 on success, a negative APTP_E* code otherwise; aptp_last_error() gives a thread-local message.
+ */
+#ifndef APTP_HIP_H
+#define APTP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* aptp_stream_t; /* hipStream_t */
+
+enum {
+  APTP_OK = 0,
+  APTP_EINVAL = -1,   /* bad shape / alignment / null pointer */
+  APTP_ELAUNCH = -2,  /* hipLaunch failed */
+  APTP_EWORKSPACE = -3
+};
+
+enum { APTP_ACT_NONE = 0, APTP_ACT_SILU = 1, APTP_ACT_GEGLU = 2 };
+
+/*
+ * Implicit-GEMM convolution / linear:  y[m, n] = epilogue( sum_{tap,c} x[pix(m,tap), c] * w[n, tap, c] )
+ *   m = (b, oy, ox) over B*Hout*Wout,  pix = (b, (oy*stride - pad + ky) >> ups, (ox*stride - pad + kx) >> ups)
+ * Replaces: F.conv2d in ResnetBlock2D*.conv1/conv2/conv_shortcut (pdm/models/unet/blocks.py:331,362,364-367,
+ * 537,568,570-573), Downsample2D/Upsample2D convs (inherited diffusers; nearest-x2 folded via `ups`),
+ * conv_in/conv_out (pdm/models/unet/unet_2d_conditional.py:1614,1721), and every F.linear of the transformer
+ * path: to_q/to_k/to_v/to_out (blocks.py:228-240,266-268), GEGLU proj (blocks.py:43), ff.net[2], proj_in/proj_out
+ * (blocks.py:1239-1243,1301-1305), time_emb_proj (blocks.py:336-340), time_embedding
+ * (unet_2d_conditional.py:1519).
+ * Epilogue, in this order (each optional):
+ *   v += bias[n]; v += rowbias[b, n]                      (conv bias; + time_emb_proj(SiLU(temb)), blocks.py:342-343)
+ *   v *= colgate[b % gate_B, n / gate_group]              (WidthGate, gates.py:15-21; blocks.py:345-348, 250-255)
+ *   act: SiLU, or GEGLU on (h,g) column pairs: h * gelu_erf(g)   (blocks.py:41-50; gate applied to both halves)
+ *   v += corr[(b % corr_B), border_class(oy,ox), n]       (gated-vs-pruned GroupNorm-beta term)
+ *   v += residual[m, n]                                   (blocks.py:369, 799, 818, 849, 1308)
+ *   v = (1-d[b % depth_B]) * depth_in[m, n] + d * v       (DepthGate, gates.py:36-42; blocks.py:577-582,1345-1348)
+ */
+typedef struct {
+  const void* x;        /* bf16 [B, Hin, Win, >=Cin], row stride ldx */
+  int64_t ldx;
+  int32_t B, Hin, Win, Cin;
+  int32_t Hout, Wout;
+  int32_t KH, KW, stride, pad, ups;
+  const void* w;        /* bf16 packed [N][KH*KW][Cin_pad] */
+  int32_t N;            /* GEMM N (for GEGLU: 2*hidden, packed in [16 h | 16 g] column blocks) */
+  int32_t cin_pad;      /* ceil(Cin/64)*64 */
+  const float* bias;    /* [N] or NULL */
+  const float* rowbias; /* [B, ld_rowbias] or NULL */
+  int32_t ld_rowbias;
+  const float* colgate; /* [gate_B, Nlogical/gate_group] or NULL */
+  int32_t gate_group, gate_B;
+  int32_t act;          /* APTP_ACT_* */
+  const float* corr;    /* [corr_B, 9, N] or NULL; class = 3*rowclass + colclass, class 1 = interior */
+  int32_t corr_B;
+  const void* residual; /* bf16 [M, ldres] or NULL */
+  int64_t ldres;
+  const float* depth;   /* [depth_B] or NULL */
+  int32_t depth_B;
+  const void* depth_in; /* bf16 [M, lddin] */
+  int64_t lddin;
+  void* y;              /* bf16 (or fp32 if out_f32) [M, ldy]; GEGLU writes N/2 columns */
+  int64_t ldy;
+  int32_t out_f32;
+  int32_t split_k;      /* >=1; >1 needs workspace of aptp_conv_gemm_workspace_bytes() */
+  void* workspace;
+  int32_t tile;         /* 0 = auto; otherwise APTP_TILE_* (testing / tuning) */
+} AptpConvGemmParams;
+
+enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TILE_64x128 = 3, APTP_TILE_64x160 = 4,
+       APTP_TILE_128x64 = 5, APTP_TILE_64x64 = 6 };
+
+int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
+int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);
+/* heuristic split-K the library would choose for this problem (host helper, no launch) */
+int aptp_conv_gemm_suggest_split_k(const AptpConvGemmParams* p);
+
+/*
+ * GroupNorm (+ optional SiLU) over channels-last bf16:  y = act((x - mean_g) * rstd_g * gamma + beta)
+ * Replaces F.group_norm + F.silu of ResnetBlock2D.norm1/norm2 + nonlinearity (blocks.py:296-301,350-359),
+ * Transformer2DModel.norm (blocks.py:1227, eps 1e-6, no SiLU) and conv_norm_out + conv_act
+ * (unet_2d_conditional.py:1718-1720).  `groups` groups of C/groups consecutive channels; statistics over
+ * (C/groups)*HW elements per (sample, group), biased variance, fp32 accumulation.
+ * C need not be a multiple of 8 (compacted channel counts such as 17 groups x 10): rows are processed in 8-channel
+ * octets, ld >= roundup8(C), and channels [C, roundup8(C)) of y are written as exact zeros.
+ * workspace: fp32 [B, nchunk, groups, 2] with nchunk = aptp_groupnorm_nchunk(HW).
+ */
+typedef struct {
+  const void* x; int64_t ldx;   /* bf16 [B*HW, >=C] */
+  void* y; int64_t ldy;         /* bf16 [B*HW, >=C] */
+  int32_t B, HW, C, groups;
+  const float* gamma; const float* beta; /* [C] */
+  float eps;
+  int32_t silu;
+  void* workspace;
+} AptpGroupNormParams;
+
+int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream);
+int aptp_groupnorm_nchunk(int HW);
+int64_t aptp_groupnorm_workspace_bytes(const AptpGroupNormParams* p);
+
+/*
+ * LayerNorm over the last dim of bf16 [rows, C]: replaces nn.LayerNorm norm1/norm2/norm3 of
+ * BasicTransformerBlock (blocks.py:782,808-810,821); eps 1e-5, affine, two-pass fp32 statistics.
+ */
+typedef struct {
+  const void* x; int64_t ldx;
+  void* y; int64_t ldy;
+  int32_t rows, C;
+  const float* gamma; const float* beta;
+  float eps;
+} AptpLayerNormParams;
+
+int aptp_layernorm(const AptpLayerNormParams* p, aptp_stream_t stream);
+
+/*
+ * Scaled-dot-product attention, head_dim 64, no mask, no dropout: o = softmax(q k^T * scale) v per (batch, head).
+ * Replaces F.scaled_dot_product_attention in HeadGatedAttnProcessor2 (blocks.py:258-260).
+ * q/k/v/o are bf16 with layout [B, L, heads, 64] expressed through strides (elements): element (b, l, h, d) at
+ * ptr + b*stride_b + l*stride_l + h*64 + d, so fused QKV / KV GEMM outputs are consumed in place.
+ */
+typedef struct {
+  const void* q; int64_t q_stride_b, q_stride_l;
+  const void* k; int64_t k_stride_b, k_stride_l;
+  const void* v; int64_t v_stride_b, v_stride_l;
+  void* o; int64_t o_stride_b, o_stride_l;
+  int32_t B, heads, Lq, Lk;
+  float scale;
+} AptpAttentionParams;
+
+int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream);
+
+const char* aptp_last_error(void);
+int aptp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APTP_HIP_H */

@@ -1,0 +1,271 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch fp32 references.
+
+Tolerances (bf16 operands, fp32 accumulate): relative L2 error <= 4e-3 per op against an fp32
+reference evaluated on the SAME bf16-rounded inputs (so only accumulation order and the bf16 output rounding
+differ), max-abs error bounded by a few bf16 ulps of the output scale.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 4e-3
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def _rand(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale)
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    from diffusion_pruning_amd import ops as o
+    o._lib.load()
+    return o
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, ups, tile, split_k
+    (2, 16, 16, 64, 64, 3, 1, 0, 0, 1),
+    (1, 8, 8, 320, 320, 3, 1, 0, 0, None),
+    (2, 32, 32, 160, 320, 3, 1, 0, 2, 1),      # Cin not multiple of 64 (zero-padded K chunk), 128x160 tile
+    (2, 32, 32, 160, 320, 3, 1, 0, 4, 1),      # 64x160 tile
+    (2, 16, 16, 128, 128, 3, 2, 0, 0, 1),      # stride-2 downsample
+    (2, 8, 8, 128, 128, 3, 1, 1, 0, 1),        # nearest-x2 upsample folded in
+    (2, 16, 16, 192, 128, 1, 1, 0, 0, 1),      # 1x1 shortcut
+    (3, 7, 5, 72, 40, 3, 1, 0, 0, 1),          # ragged M / N / Cin tails
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 3, 4),      # split-K
+    (1, 8, 8, 2560, 1280, 3, 1, 0, 0, None),   # auto split-K, K = 23040
+    (4, 8, 8, 64, 64, 3, 1, 0, 1, 1),          # 128x128 tile
+    (4, 8, 8, 64, 64, 3, 1, 0, 5, 1),          # 128x64 tile
+    (4, 8, 8, 64, 64, 3, 1, 0, 6, 2),          # 64x64 tile + split-K
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_plain(ops, cuda, case):
+    B, H, W, Cin, Cout, k, stride, ups, tile, split_k = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = _rand((B, Cin, H, W), g).bfloat16()
+    w = _rand((Cout, Cin, k, k), g, 1.0 / math.sqrt(Cin * k * k)).bfloat16()
+    b = _rand((Cout,), g, 0.1)
+    pw = ops.pack_weight(w.float(), b, device=cuda)
+    y = ops.conv_gemm(nhwc(x).to(cuda), pw, stride=stride, ups=ups, tile=tile, split_k=split_k)
+    xr = x.float()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xr, w.float(), b, stride=stride, padding=k // 2)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    e = rel_l2(got, ref)
+    assert e <= REL_L2_TOL, f"rel-L2 {e:.3e}"
+
+
+def test_conv_strided_views(ops, cuda):
+    """input is a channel slice of a wider buffer, output written into a slice of a wider buffer"""
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Cin, Cout = 2, 8, 8, 64, 96
+    x = _rand((B, Cin, H, W), g).bfloat16()
+    w = _rand((Cout, Cin, 3, 3), g, 0.05).bfloat16()
+    pw = ops.pack_weight(w.float(), None, device=cuda)
+    wide_in = torch.full((B, H, W, 160), float("nan"), dtype=torch.bfloat16, device=cuda)
+    wide_in[..., 32:96] = nhwc(x).to(cuda)
+    wide_out = torch.zeros(B, H, W, 256, dtype=torch.bfloat16, device=cuda)
+    ops.conv_gemm(wide_in[..., 32:96], pw, out=wide_out[..., 64:160])
+    ref = F.conv2d(x.float(), w.float(), None, padding=1)
+    got = wide_out[..., 64:160].float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) <= REL_L2_TOL
+    assert float(wide_out[..., :64].abs().max()) == 0.0 and float(wide_out[..., 160:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("split_k", [1, 3])
+def test_conv_full_epilogue(ops, cuda, split_k):
+    """bias + temb rowbias + per-sample width gate, then (separately) corr + residual + depth lerp"""
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout, G = 4, 8, 8, 64, 64, 32
+    x = _rand((B, Cin, H, W), g).bfloat16()
+    w = _rand((Cout, Cin, 3, 3), g, 0.05).bfloat16()
+    b = _rand((Cout,), g, 0.1)
+    pw = ops.pack_weight(w.float(), b, device=cuda)
+    temb = _rand((B, Cout), g, 0.5)
+    gate = torch.rand((2, G), generator=g)                     # Bg=2 tiled over B=4 (CFG layout)
+    y = ops.conv_gemm(nhwc(x).to(cuda), pw, rowbias=temb.to(cuda), colgate=gate.to(cuda).contiguous(),
+                      gate_group=Cout // G, split_k=split_k)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1) + temb[:, :, None, None]
+    mask = gate.repeat_interleave(Cout // G, dim=1).repeat(2, 1)[:, :, None, None]
+    ref = ref * mask
+    assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), ref) <= REL_L2_TOL
+
+    res = _rand((B, Cout, H, W), g).bfloat16()
+    din = _rand((B, Cout, H, W), g).bfloat16()
+    d = torch.rand((2,), generator=g)
+    corr = _rand((1, 9, Cout), g, 0.3)
+    y = ops.conv_gemm(nhwc(x).to(cuda), pw, corr=corr.to(cuda).contiguous(), residual=nhwc(res).to(cuda),
+                      depth=d.to(cuda), depth_in=nhwc(din).to(cuda), split_k=split_k)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    cls = torch.ones(H, dtype=torch.long); cls[0] = 0; cls[-1] = 2
+    cmap = cls[:, None] * 3 + cls[None, :]                      # [H, W]
+    ref = ref + corr[0][cmap].permute(2, 0, 1)[None]
+    ref = ref + res.float()
+    dm = d.repeat(2)[:, None, None, None]
+    ref = (1 - dm) * din.float() + dm * ref
+    assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), ref) <= REL_L2_TOL
+
+
+@pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6)])
+def test_linear_geglu(ops, cuda, split_k, tile):
+    g = torch.Generator().manual_seed(13)
+    B, L, C, inner = 2, 96, 64, 256
+    x = _rand((B, L, C), g).bfloat16()
+    w = _rand((2 * inner, C), g, 0.125).bfloat16()
+    b = _rand((2 * inner,), g, 0.1)
+    gate = (torch.rand((B, 32), generator=g) > 0.3).float()
+    pw = ops.pack_weight(w.float(), b, geglu=True, device=cuda)
+    y = ops.linear(x.to(cuda), pw, colgate=gate.to(cuda).contiguous(), gate_group=inner // 32, split_k=split_k, tile=tile)
+    hcat = F.linear(x.float(), w.float(), b)
+    h, gg = hcat.chunk(2, dim=-1)
+    m = gate.repeat_interleave(inner // 32, dim=1)[:, None, :]
+    ref = (h * m) * F.gelu(gg * m)
+    assert y.shape == ref.shape
+    assert rel_l2(y.float().cpu(), ref) <= REL_L2_TOL
+
+
+def test_linear_compact_geglu_and_silu_f32(ops, cuda):
+    g = torch.Generator().manual_seed(17)
+    B, L, C, inner = 1, 50, 128, 512
+    x = _rand((B, L, C), g).bfloat16()
+    w = _rand((2 * inner, C), g, 0.09).bfloat16()
+    b = _rand((2 * inner,), g, 0.1)
+    keep = torch.arange(inner)[(torch.arange(inner) // 16) % 3 != 1]     # arbitrary live hidden units
+    pw = ops.pack_weight(w.float(), b, geglu=True, out_idx=keep, device=cuda)
+    y = ops.linear(x.to(cuda), pw)
+    hcat = F.linear(x.float(), w.float(), b)
+    h, gg = hcat.chunk(2, dim=-1)
+    ref = (h * F.gelu(gg))[..., keep]
+    n = keep.numel()
+    assert rel_l2(y.float().cpu()[..., :n], ref) <= REL_L2_TOL
+    assert float(y[..., n:].abs().max()) == 0.0 if y.shape[-1] > n else True
+    # SiLU epilogue with fp32 output (time embedding MLP)
+    w2 = _rand((96, C), g, 0.09).bfloat16()
+    pw2 = ops.pack_weight(w2.float(), None, device=cuda)
+    y2 = ops.linear(x.to(cuda), pw2, act=ops.ACT_SILU, out_f32=True)
+    assert y2.dtype == torch.float32
+    assert rel_l2(y2.cpu(), F.silu(F.linear(x.float(), w2.float()))) <= 1e-5
+
+
+GN_CASES = [
+    # B, H, W, C, groups, silu, eps
+    (2, 16, 16, 64, 32, True, 1e-5),
+    (2, 8, 8, 320, 32, True, 1e-5),
+    (1, 32, 32, 320, 32, False, 1e-6),
+    (2, 8, 8, 2560, 32, True, 1e-5),     # two octet pages
+    (2, 8, 8, 1920, 32, True, 1e-5),
+    (3, 4, 4, 170, 17, True, 1e-5),      # compacted: 17 live groups of 10, padded to 176 columns
+    (2, 8, 8, 960, 32, True, 1e-5),
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES)
+def test_groupnorm(ops, cuda, case):
+    B, H, W, C, G, silu, eps = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = (_rand((B, C, H, W), g) * 2.0 + 0.7).bfloat16()
+    gamma = 1.0 + 0.2 * _rand((C,), g)
+    beta = 0.3 * _rand((C,), g)
+    Cp = ops.round_up(C, 8)
+    xin = torch.full((B, H, W, Cp), 0.0, dtype=torch.bfloat16)
+    xin[..., :C] = nhwc(x)
+    y = ops.groupnorm(xin.to(cuda), gamma.to(cuda), beta.to(cuda), G, eps, silu, C=C)
+    ref = F.group_norm(x.float(), G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    got = y.float().cpu()
+    assert rel_l2(got[..., :C].permute(0, 3, 1, 2), ref) <= REL_L2_TOL
+    if Cp > C:
+        assert float(got[..., C:].abs().max()) == 0.0
+
+
+def test_groupnorm_zero_group_gives_beta(ops, cuda):
+    """a fully zeroed group normalises to exactly beta"""
+    B, H, W, C, G = 1, 8, 8, 64, 32
+    g = torch.Generator().manual_seed(3)
+    x = _rand((B, H, W, C), g).bfloat16()
+    x[..., 10:12] = 0
+    gamma = torch.ones(C)
+    beta = 0.25 * torch.arange(C, dtype=torch.float32) / C
+    y = ops.groupnorm(x.to(cuda), gamma.to(cuda), beta.to(cuda), G, 1e-5, False)
+    assert torch.equal(y[..., 10:12].float().cpu(), beta[10:12].bfloat16().float().expand(B, H, W, 2))
+
+
+@pytest.mark.parametrize("rows,C", [(7, 64), (128, 320), (130, 640), (33, 1280)])
+def test_layernorm(ops, cuda, rows, C):
+    g = torch.Generator().manual_seed(rows * C)
+    x = (_rand((1, rows, C), g) * 1.5 + 0.4).bfloat16()
+    gamma = 1.0 + 0.2 * _rand((C,), g)
+    beta = 0.3 * _rand((C,), g)
+    y = ops.layernorm(x.to(cuda), gamma.to(cuda), beta.to(cuda), 1e-5)
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    assert rel_l2(y.float().cpu(), ref) <= REL_L2_TOL
+
+
+ATTN_CASES = [
+    # B, heads, Lq, Lk
+    (1, 1, 64, 64),
+    (2, 2, 256, 256),
+    (2, 5, 1024, 1024),
+    (2, 3, 256, 77),       # cross attention, ragged key tile
+    (1, 2, 100, 77),       # ragged queries too
+    (1, 4, 64, 200),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention(ops, cuda, case):
+    B, h, Lq, Lk = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    q = _rand((B, Lq, h * 64), g).bfloat16()
+    k = _rand((B, Lk, h * 64), g).bfloat16()
+    v = _rand((B, Lk, h * 64), g).bfloat16()
+    o = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), h)
+
+    def heads(t, L):
+        return t.float().view(B, L, h, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(heads(q, Lq), heads(k, Lk), heads(v, Lk))
+    ref = ref.transpose(1, 2).reshape(B, Lq, h * 64)
+    e = rel_l2(o.float().cpu(), ref)
+    assert e <= 6e-3, f"rel-L2 {e:.3e}"   # P is rounded to bf16 before P.V (as any bf16 flash kernel does)
+
+
+def test_attention_fused_qkv_views_and_spike(ops, cuda):
+    """q/k/v as column slices of one fused buffer; one key spiked so the running max jumps mid-sequence"""
+    g = torch.Generator().manual_seed(5)
+    B, h, L = 2, 2, 320
+    qkv = _rand((B, L, 3 * h * 64), g).bfloat16()
+    qkv[:, 200, h * 64:2 * h * 64] *= 6.0      # large-norm key in the 4th key tile
+    dq = qkv.to(cuda)
+    o = ops.attention(dq[..., :h * 64], dq[..., h * 64:2 * h * 64], dq[..., 2 * h * 64:], h)
+
+    def heads(t):
+        return t.float().reshape(B, L, h, 64).transpose(1, 2)
+    q, k, v = qkv[..., :h * 64], qkv[..., h * 64:2 * h * 64], qkv[..., 2 * h * 64:]
+    ref = F.scaled_dot_product_attention(heads(q), heads(k), heads(v)).transpose(1, 2).reshape(B, L, h * 64)
+    assert rel_l2(o.float().cpu(), ref) <= 6e-3
+
+
+def test_bad_arguments_fail_loudly(ops, cuda):
+    from diffusion_pruning_amd._lib import AptpError
+    x = torch.zeros(1, 4, 4, 12, dtype=torch.bfloat16, device=cuda)   # Cin not a multiple of 8
+    pw = ops.pack_weight(torch.zeros(8, 12, 3, 3), None, cin_pad_to=1, device=cuda)
+    with pytest.raises((AptpError, ValueError)):
+        ops.conv_gemm(x, pw)

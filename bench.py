@@ -1,0 +1,221 @@
+"""Headline benchmark: masked SD-2.1 U-Net denoise steps per second on MI355X (BASELINE.json configs[1]).
+
+A "step" is one UNet2DConditionModelGated.forward on a [4,4,64,64] latent batch (512x512 images, bs=4), fixed 50 %
+channel mask, synthetic latents / text states / seeded random-init weights, inputs resident in HBM.
+The whole forward is captured once into a HIP graph and replayed; K replays are timed between
+barrier + torch.cuda.synchronize().  Multi-GPU = independent replicas (inference shards by prompt, no
+data-path collective): one process per GPU, MAX time over ranks, value = all ranks' steps / that time.
+
+Prints ONE JSON line (see the task contract) with two extra objects:
+  roofline      MFMA roofline of the dominant kernel family (conv_gemm_kernel<*>, implicit-GEMM conv/linear): achieved =
+                algorithmic FLOPs of all its launches in one forward / their measured device time (HIP events around a
+                graph that replays exactly those launches), peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (PyTorch CPU restatement, fp32) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def fixed_half_mask(structure, device):
+    """every 32-wide gate keeps even entries, head gates keep the first floor(h/2) heads, all depth gates on"""
+    width = []
+    for sub in structure["width"]:
+        for w in sub:
+            g = torch.zeros(1, w, device=device)
+            if w == 32:
+                g[:, 0::2] = 1.0
+            else:
+                g[:, :max(1, w // 2)] = 1.0
+            width.append(g)
+    depth = [torch.ones(1, device=device) for sub in structure["depth"] for d in sub if d == 1]
+    return {"width": width, "depth": depth}
+
+
+def ones_mask(structure, device):
+    return {"width": [torch.ones(1, w, device=device) for sub in structure["width"] for w in sub],
+            "depth": [torch.ones(1, device=device) for sub in structure["depth"] for d in sub if d == 1]}
+
+
+def algorithmic_flops(masked: bool, batch: int, latent: int) -> float:
+    """matmul-only FLOPs of one forward: 223.67 GMAC masked / 402.13 GMAC dense per sample @64x64"""
+    assert latent == 64
+    return 2.0 * (223.66507008e9 if masked else 402.12668416e9) * batch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--dense", action="store_true", help="mask == 1 instead of the fixed 50 %% mask")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from diffusion_pruning_amd import ops
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+
+    model = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
+    structure = model.get_structure()
+    model.set_structure(ones_mask(structure, dev) if args.dense else fixed_half_mask(structure, dev))
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    B, L = args.batch, args.latent
+    sample = torch.randn(B, 4, L, L, generator=g).to(dev)
+    ehs = torch.randn(B, 77, 1024, generator=g).to(dev)
+    t = torch.full((B,), 500, dtype=torch.int64, device=dev)
+
+    def step():
+        return model(sample, t, ehs, return_dict=False)[0]
+
+    with torch.no_grad():
+        out = step()                      # builds the packed-weight plans
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        if args.no_graph:
+            run = step
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gout = step()
+            run = graph.replay
+
+        def barrier():
+            if world > 1:
+                torch.distributed.barrier()
+
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(te.item())
+
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+
+        roofline = None
+        cpu_baseline = None
+        if rank == 0:
+            roofline = measure_roofline(ops, step, dev)
+            flops = algorithmic_flops(not args.dense, B, L)
+            roofline["whole_step_tflops"] = round(flops / (ms_per_step * 1e-3) / 1e12, 1)
+            if world == 1 and not args.no_cpu_baseline:
+                cpu_baseline = measure_cpu_baseline(model, args.dense)
+
+    if rank == 0:
+        line = {
+            "metric": "denoise-steps/s (SD-2.1 U-Net forward, 512x512, bs=4 per GPU, 50% channel mask)" if not args.dense
+                      else "denoise-steps/s (SD-2.1 U-Net forward, 512x512, bs=4 per GPU, dense)",
+            "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SD-2.1 UNet2DConditionModelGated.forward, 64x64 latents "
+                                   f"(512x512), bs={B}/GPU, " + ("mask=1" if args.dense else "fixed 50% mask (gated semantics)")
+                                   + ", seeded random-init weights, HIP graph replay",
+                       "global_batch": B * world, "parallelism": f"replicas x{world} (no data-path collective)"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def measure_roofline(ops, step, dev):
+    """Device time of every conv_gemm launch of one forward (the dominant kernel family), measured with HIP events on
+    the launch stream around a HIP graph that replays exactly those launches."""
+    lib = ops._lib.load()
+    ops.LAUNCH_LOG = []
+    step()
+    torch.cuda.synchronize()
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        def replay_all():
+            s = torch.cuda.current_stream().cuda_stream
+            for rec in log:
+                rc = lib.aptp_conv_gemm(ctypes.byref(rec["params"]), s)
+                assert rc == 0
+        replay_all()
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            replay_all()
+        reps = 10
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(stream)
+        stream.synchronize()
+        total_ms = e0.elapsed_time(e1) / reps
+    flops = sum(r["flops"] for r in log)
+    n = len(log)
+    achieved = flops / (total_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_gemm_kernel<BM,BN,2,2> (implicit-GEMM conv/linear, all tile instantiations)",
+            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "traffic": None, "launches_per_step": n, "avg_launch_us": round(total_ms * 1e3 / n, 2),
+            "family_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(flops / 1e9, 1)}
+
+
+def measure_cpu_baseline(model, dense):
+    """The oracle (PyTorch CPU fp32 restatement of the reference's diffusers path) on this host: one denoise step at
+    bs=1 of the same workload (a quarter of the bs=4 batch), all host cores."""
+    from oracle import unet_oracle as O
+    cfg = O.SD21
+    params = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    sample, t, ehs = O.synthetic_inputs(cfg, 1, 64)
+    mask = O.ones_mask(cfg) if dense else O.fixed_half_mask(cfg)
+    gates = O.assign_gates(cfg, mask)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.unet_forward(params, cfg, sample, t, ehs, gates, "gated")
+        dt = time.perf_counter() - t0
+    return {"value": round(1.0 / (4.0 * dt), 5), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 denoise step at bs=1 (1/4 of the bs=4 step) in {dt:.2f} s, gated semantics (dense compute + mask "
+                      f"multiply as the reference does), fp32, torch {torch.__version__} CPU; value = 1/(4*t)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,10 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out_idx
 
 _ws_cache = {}
 
+# Optional launch recorder used by bench.py's roofline leg: when a list, every aptp_conv_gemm launch appends
+# {"params": ConvGemmParams, "flops": algorithmic FLOPs, "keep": tensors referenced by the params}.
+LAUNCH_LOG = None
+
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per device (stream-ordered reuse: kernels on one stream serialise)."""
@@ -216,6 +220,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         ws = _workspace(lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(p)), x.device)
         p.workspace = ws.data_ptr()
     _lib.check(lib.aptp_conv_gemm(ctypes.byref(p), _stream()), "aptp_conv_gemm")
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * pw.KH * pw.KW * pw.Cin,
+                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws)})
     return out
 
 

@@ -1,0 +1,1117 @@
+"""Gated SD-2.1 U-Net on the HIP path, behind the reference's Python API.
+
+Mirrors (same class names, call signatures, structure plumbing, state-dict keys):
+  pdm/models/unet/unet_2d_conditional.py  UNet2DConditionModelGated (:628-2181; forward :1415-1726,
+                                          get_structure :1332-1363, set_structure :1365-1413, freeze :2118-2122),
+                                          UNet2DConditionModelPruned (:2184-2472)
+  pdm/models/unet/blocks.py               ResnetBlock2DWidthGated (:283-465), ResnetBlock2DWidthDepthGated (:468-697),
+                                          GatedAttention (:132-187), GEGLUGated/FeedForwardWidthGated (:24-129),
+                                          BasicTransformerBlockWidthGated (:700-938), Transformer2DModelWidthGated
+                                          (:941-1067), Transformer2DModelWidthDepthGated (:1070-1438), containers
+                                          (:1677-1909, 2004-2243, 2290-2416, 2419-2550, 2554-2736)
+
+Differences that matter (all deliberate):
+  * Compute never touches torch.nn.functional: every block launches the hand-written gfx950 kernels of
+    libaptp_hip.so through ``ops`` (and fails loudly if the library or the GPU is missing).
+  * Activations travel as logical [B,C,H,W] bf16 tensors in channels_last memory (= NHWC for the kernels), so the
+    NCHW<->token permutes of the reference vanish and block outputs keep the diffusers shapes for forward hooks.
+  * A gate is not a separate elementwise pass.  Hard masks shared by the batch compact the weights once per
+    ``set_structure`` (dead conv1 output groups / conv2 input groups / heads / FF chunks are never computed; the
+    GroupNorm-beta term that distinguishes *gated* from *pruned* semantics is restored exactly by a 9-class border
+    correction in the conv2 epilogue).  Soft or per-sample masks run dense with the mask fused into the epilogue of
+    the producing GEMM, exactly the reference's arithmetic order.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .gates import DepthGate, LinearWidthGate, WidthGate
+from .ops import PackedWeight
+
+# ----------------------------------------------------------------------------------------------------------------
+# parameter containers (diffusers names / shapes at the state-dict boundary; never called)
+# ----------------------------------------------------------------------------------------------------------------
+
+
+class _Params(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container; the owning block launches the HIP kernels")
+
+
+class Conv2dP(_Params):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = cin, cout, (k, k)
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+
+
+class LinearP(_Params):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = cin, cout
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+
+
+class NormP(_Params):
+    def __init__(self, c, eps, groups=None):
+        super().__init__()
+        self.num_channels, self.eps, self.num_groups = c, eps, groups
+        self.weight = nn.Parameter(torch.empty(c))
+        self.bias = nn.Parameter(torch.empty(c))
+
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    """logical NCHW (channels_last memory) -> NHWC view"""
+    return x.permute(0, 2, 3, 1)
+
+
+def _nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2)
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float().contiguous()
+
+
+@dataclass
+class TembBundle:
+    """SiLU(emb) plus the batched time_emb_proj outputs of every resnet (one GEMM per forward)."""
+    emb_silu: torch.Tensor                   # bf16 [B, T]
+    proj: Dict[int, torch.Tensor] = field(default_factory=dict)   # id(resnet) -> fp32 [B, Npad] view
+
+
+@dataclass
+class CtxBundle:
+    """Text states plus the batched cross-attention K/V projections of every attn2 (one GEMM per forward)."""
+    ehs: torch.Tensor                        # bf16 [B, 77, X]
+    kv: Dict[int, torch.Tensor] = field(default_factory=dict)     # id(attn2) -> bf16 [B, 77, 2*hl*64] view
+
+
+def _live_index(mask: torch.Tensor, group: int) -> torch.Tensor:
+    """channel indices kept by a {0,1} mask over groups of `group` consecutive channels"""
+    g = torch.nonzero(mask > 0.5).flatten()
+    return (g[:, None] * group + torch.arange(group)[None, :]).flatten()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ResNet blocks
+# ----------------------------------------------------------------------------------------------------------------
+class ResnetBlock2DWidthGated(nn.Module):
+    """blocks.py:283-465.  GN32->SiLU->conv3x3->+time_emb_proj(SiLU(temb))->width gate->GN32->SiLU->conv3x3
+    ->(+1x1 shortcut)->+x."""
+    depth_gated = False
+
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, groups: int = 32, eps: float = 1e-5,
+                 is_input_concatenated: bool = False, skip_connection_dim: Optional[int] = None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.groups, self.eps = in_channels, out_channels, groups, eps
+        self.norm1 = NormP(in_channels, eps, groups)
+        self.conv1 = Conv2dP(in_channels, out_channels, 3)
+        self.time_emb_proj = LinearP(temb_channels, out_channels)
+        self.norm2 = NormP(out_channels, eps, groups)
+        self.conv2 = Conv2dP(out_channels, out_channels, 3)
+        self.conv_shortcut = Conv2dP(in_channels, out_channels, 1) if in_channels != out_channels else None
+        self.gate = WidthGate(groups)
+        self.is_input_concatenated = is_input_concatenated
+        self.skip_connection_dim = skip_connection_dim
+        self.structure = {"width": [], "depth": []}
+        self.prunable_macs, self.total_macs = 0.0, 0.0
+        self.pruned = False
+        self.dropped = False
+        self.semantics = "gated"
+        self._plans: Dict[Any, dict] = {}
+
+    # ---- structure plumbing (blocks.py:373-382) -----------------------------------------------------------------
+    def get_gate_structure(self):
+        if not self.structure["width"]:
+            self.structure = {"width": [self.gate.width], "depth": [1 if self.depth_gated else 0]}
+        return self.structure
+
+    def set_gate_structure(self, arch_vectors):
+        assert len(arch_vectors["depth"]) == (1 if self.depth_gated else 0)
+        assert len(arch_vectors["width"]) == 1
+        assert arch_vectors["width"][0].shape[1] == self.gate.width
+        self.gate.set_structure_value(arch_vectors["width"][0])
+        if self.depth_gated:
+            self.depth_gate.set_structure_value(arch_vectors["depth"][0])
+
+    def invalidate(self):
+        self._plans.clear()
+
+    # ---- execution plan -----------------------------------------------------------------------------------------
+    def _mask_key(self):
+        m = self.gate.hard_uniform()
+        return None if m is None else tuple(int(v) for v in m.tolist())
+
+    def plan(self, device) -> dict:
+        """Packed (and, for a hard batch-shared mask, compacted) weights for the current gate value."""
+        key = (self._mask_key(), self.semantics, str(device))
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        if len(self._plans) >= 4:
+            self._plans.pop(next(iter(self._plans)))
+        mask = self.gate.hard_uniform()
+        cg = self.out_channels // self.groups
+        pl = {"compact": mask is not None and not bool((mask == 1).all())}
+        dev = device
+        if mask is not None and float(mask.sum()) == 0:
+            raise ValueError("width gate with no live group (the reference forbids it: non_zero_width)")
+        if pl["compact"]:
+            live = _live_index(mask, cg)
+            dead = _live_index(1 - mask, cg)
+            k_live = int(mask.sum())
+        else:
+            live, dead, k_live = None, None, self.groups
+        c_live = k_live * cg
+        pl["k_live"], pl["c_live"], pl["c_pad"] = k_live, c_live, ops.round_up(c_live, 8)
+        pl["w1"] = ops.pack_weight(self.conv1.weight.detach(), self.conv1.bias.detach(), out_idx=live, device=dev)
+        # time_emb_proj rows (+bias) are gathered the same way and batched by the model into one GEMM
+        wt, bt = _f32(self.time_emb_proj.weight), _f32(self.time_emb_proj.bias)
+        if live is not None:
+            wt, bt = wt[live.to(wt.device)], bt[live.to(bt.device)]
+        pl["temb_w"], pl["temb_b"] = wt, bt
+        g2, b2 = _f32(self.norm2.weight), _f32(self.norm2.bias)
+        if live is not None:
+            g2, b2 = g2[live.to(g2.device)], b2[live.to(b2.device)]
+        pl["g2"], pl["b2"] = g2.to(dev), b2.to(dev)
+        pl["g1"], pl["b1"] = _f32(self.norm1.weight).to(dev), _f32(self.norm1.bias).to(dev)
+        pl["w2"] = ops.pack_weight(self.conv2.weight.detach(), self.conv2.bias.detach(), in_idx=live, device=dev)
+        pl["wsc"] = None
+        if self.conv_shortcut is not None:
+            pl["wsc"] = ops.pack_weight(self.conv_shortcut.weight.detach(), self.conv_shortcut.bias.detach(), device=dev)
+        pl["corr"] = None
+        if pl["compact"] and self.semantics == "gated":
+            # a zeroed group leaves GroupNorm as beta, so conv2 of the *gated* model still sees
+            # SiLU(beta_c) on dead channels; restore that term exactly per border class (zero padding removes taps).
+            w2 = _f32(self.conv2.weight).to(dev)[:, dead.to(dev)]
+            sb = torch.nn.functional.silu(_f32(self.norm2.bias).to(dev)[dead.to(dev)])
+            T = torch.einsum("ncyx,c->nyx", w2, sb)                       # [Cout, 3, 3]
+            valid = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}
+            corr = torch.zeros(1, 9, self.out_channels, device=dev)
+            for rc in range(3):
+                for cc in range(3):
+                    corr[0, rc * 3 + cc] = T[:, list(valid[rc])][:, :, list(valid[cc])].sum(dim=(1, 2))
+            pl["corr"] = corr.contiguous()
+        self._plans[key] = pl
+        return pl
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def _depth_state(self):
+        return None, None   # (hard value or None, tensor or None)
+
+    def forward(self, input_tensor: torch.Tensor, temb, scale: float = 1.0):
+        x = _nhwc(input_tensor)
+        dev = x.device
+        pl = self.plan(dev)
+        B, H, W, Cin = x.shape
+        assert Cin == self.in_channels
+        x_in = x[..., :Cin - self.skip_connection_dim] if (self.depth_gated and self.is_input_concatenated) else x
+        d_hard, d_vec = self._depth_state()
+        if self.depth_gated and (self.dropped or d_hard == 0.0):
+            return _nchw(x_in)                                            # blocks.py:497-498 / (1-0)*x_in + 0*out
+        a1 = ops.groupnorm(x, pl["g1"], pl["b1"], self.groups, self.eps, True)
+        rowbias = self._temb_rowbias(temb, pl, B)
+        gate_kw = {}
+        if not pl["compact"] and self.gate.hard_uniform() is None:
+            gate_kw = dict(colgate=self._gate_dev(dev), gate_group=self.out_channels // self.groups)
+        h = ops.conv_gemm(a1, pl["w1"], rowbias=rowbias, **gate_kw)
+        a2 = ops.groupnorm(h, pl["g2"], pl["b2"], pl["k_live"], self.eps, True, C=pl["c_live"])
+        sc = x if pl["wsc"] is None else ops.conv_gemm(x, pl["wsc"], pad=0)
+        dkw = {}
+        if self.depth_gated and d_hard is None:
+            dkw = dict(depth=d_vec, depth_in=x_in)
+        out = ops.conv_gemm(a2, pl["w2"], corr=pl["corr"], residual=sc, **dkw)
+        return _nchw(out)
+
+    def _gate_dev(self, dev):
+        g = self.gate.gate_f
+        return g.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+    def _temb_rowbias(self, temb, pl, B):
+        if isinstance(temb, TembBundle):
+            rb = temb.proj.get(id(self))
+            if rb is not None:
+                return rb
+            emb_silu = temb.emb_silu
+        else:
+            # standalone use with a raw [B, T] embedding: SiLU then this block's own projection
+            emb_silu = torch.nn.functional.silu(temb.float()).to(torch.bfloat16)
+        pw = pl.get("temb_pw")
+        if pw is None:
+            pw = ops.pack_weight(pl["temb_w"], pl["temb_b"], device=emb_silu.device)
+            pl["temb_pw"] = pw
+        return ops.linear(emb_silu[None], pw, out_f32=True)[0]
+
+
+class ResnetBlock2DWidthDepthGated(ResnetBlock2DWidthGated):
+    """blocks.py:468-697: adds the depth gate (1-d)*x_in + d*out and the skip-concat un-slicing for up blocks."""
+    depth_gated = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.depth_gate = DepthGate(1)
+        if self.is_input_concatenated:
+            assert self.skip_connection_dim is not None
+
+    def _depth_state(self):
+        h = self.depth_gate.host_value().flatten()
+        if bool(((h == 0) | (h == 1)).all()) and bool((h == h[0]).all()):
+            return float(h[0]), None
+        return None, self.depth_gate.gate_f.detach().flatten().to(dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# attention / feed-forward parameter holders with the reference's module names
+# ----------------------------------------------------------------------------------------------------------------
+class GatedAttention(nn.Module):
+    """blocks.py:132-187 (+ HeadGatedAttnProcessor2 :190-280): parameters and the per-head gate."""
+
+    def __init__(self, query_dim: int, heads: int, dim_head: int = 64, cross_attention_dim: Optional[int] = None):
+        super().__init__()
+        assert dim_head == 64, "the HIP attention kernel is specialised for head_dim 64 (SD-2.1)"
+        inner = heads * dim_head
+        kv_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.heads, self.inner_dim, self.is_cross = heads, inner, cross_attention_dim is not None
+        self.to_q = LinearP(query_dim, inner, bias=False)
+        self.to_k = LinearP(kv_dim, inner, bias=False)
+        self.to_v = LinearP(kv_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([LinearP(inner, query_dim), nn.Identity()])
+        self.gate = WidthGate(heads)
+        self.prunable_macs, self.total_macs = 0.0, 0.0
+        self.pruned = False
+
+
+class GEGLUGated(nn.Module):
+    """blocks.py:24-67"""
+
+    def __init__(self, dim_in: int, dim_out: int, gate_width: int = 32):
+        super().__init__()
+        self.dim_out = dim_out
+        self.proj = LinearP(dim_in, dim_out * 2)
+        self.gate = LinearWidthGate(gate_width)
+        self.pruned = False
+
+
+class FeedForwardWidthGated(nn.Module):
+    """blocks.py:70-129: net = [GEGLUGated, Dropout, Linear]"""
+
+    def __init__(self, dim: int, mult: int = 4, gate_width: int = 32):
+        super().__init__()
+        inner = dim * mult
+        self.net = nn.ModuleList([GEGLUGated(dim, inner, gate_width), nn.Identity(), LinearP(inner, dim)])
+        self.prunable_macs, self.total_macs = 0.0, 0.0
+
+
+class BasicTransformerBlockWidthGated(nn.Module):
+    """blocks.py:700-938 (parameters + structure plumbing; executed by the owning Transformer2DModel*)."""
+
+    def __init__(self, dim: int, num_attention_heads: int, attention_head_dim: int, cross_attention_dim: int,
+                 gated_ff: bool = True, ff_gate_width: int = 32):
+        super().__init__()
+        self.norm1 = NormP(dim, 1e-5)
+        self.attn1 = GatedAttention(dim, num_attention_heads, attention_head_dim, None)
+        self.norm2 = NormP(dim, 1e-5)
+        self.attn2 = GatedAttention(dim, num_attention_heads, attention_head_dim, cross_attention_dim)
+        self.norm3 = NormP(dim, 1e-5)
+        self.gated_ff = gated_ff
+        self.ff = FeedForwardWidthGated(dim, gate_width=ff_gate_width)
+        self.structure = {"width": [], "depth": []}
+
+    def get_gate_structure(self):
+        if len(self.structure["width"]) == 0:
+            self.structure["width"] = [self.attn1.gate.width, self.attn2.gate.width]
+            if self.gated_ff:
+                self.structure["width"].append(self.ff.net[0].gate.width)
+            self.structure["depth"] = [0]
+        return self.structure
+
+    def set_gate_structure(self, arch_vectors):
+        assert len(arch_vectors["depth"]) == 0
+        assert len(arch_vectors["width"]) >= 2
+        assert arch_vectors["width"][0].shape[1] == self.attn1.gate.width
+        self.attn1.gate.set_structure_value(arch_vectors["width"][0])
+        assert arch_vectors["width"][1].shape[1] == self.attn2.gate.width
+        self.attn2.gate.set_structure_value(arch_vectors["width"][1])
+        if self.gated_ff:
+            assert len(arch_vectors["width"]) == 3
+            assert arch_vectors["width"][2].shape[1] == self.ff.net[0].gate.width
+            self.ff.net[0].gate.set_structure_value(arch_vectors["width"][2])
+
+
+class Transformer2DModelWidthGated(nn.Module):
+    """blocks.py:941-1067 (forward inherited from diffusers Transformer2DModel, use_linear_projection=True):
+    GN(32, eps 1e-6) -> proj_in -> [LN->self-attn->+res; LN->cross-attn->+res; LN->GEGLU FF->+res] -> proj_out -> +x."""
+    depth_gated = False
+
+    def __init__(self, num_attention_heads: int, attention_head_dim: int, in_channels: int, cross_attention_dim: int,
+                 norm_num_groups: int = 32, gated_ff: bool = True, ff_gate_width: int = 32):
+        super().__init__()
+        C = num_attention_heads * attention_head_dim
+        assert C == in_channels
+        self.in_channels, self.heads, self.groups = in_channels, num_attention_heads, norm_num_groups
+        self.norm = NormP(in_channels, 1e-6, norm_num_groups)
+        self.proj_in = LinearP(in_channels, C)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlockWidthGated(C, num_attention_heads, attention_head_dim, cross_attention_dim,
+                                            gated_ff, ff_gate_width)])
+        self.proj_out = LinearP(C, in_channels)
+        self.structure = {"width": [], "depth": []}
+        self.prunable_macs, self.total_macs = 0.0, 0.0
+        self.pruned = False
+        self.dropped = False
+        self._plans: Dict[Any, dict] = {}
+
+    # ---- structure plumbing (blocks.py:1007-1022, 1357-1371) ------------------------------------------------------
+    def get_gate_structure(self):
+        if len(self.structure["width"]) == 0:
+            for tb in self.transformer_blocks:
+                self.structure["width"] = self.structure["width"] + tb.get_gate_structure()["width"]
+            self.structure["depth"] = [1] if self.depth_gated else [0]
+        return self.structure
+
+    def set_gate_structure(self, arch_vectors):
+        assert len(arch_vectors["depth"]) == (1 if self.depth_gated else 0)
+        if self.depth_gated:
+            self.depth_gate.set_structure_value(arch_vectors["depth"][0])
+        self.transformer_blocks[0].set_gate_structure({"width": arch_vectors["width"], "depth": []})
+
+    def invalidate(self):
+        self._plans.clear()
+
+    # ---- execution plan -------------------------------------------------------------------------------------------
+    def _keys(self):
+        tb = self.transformer_blocks[0]
+        out = []
+        for gate in (tb.attn1.gate, tb.attn2.gate, tb.ff.net[0].gate):
+            m = gate.hard_uniform()
+            out.append(None if m is None else tuple(int(v) for v in m.tolist()))
+        return tuple(out)
+
+    def plan(self, device) -> dict:
+        key = (self._keys(), str(device))
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        if len(self._plans) >= 4:
+            self._plans.pop(next(iter(self._plans)))
+        tb = self.transformer_blocks[0]
+        dev = device
+        pl = {}
+        pl["gn_g"], pl["gn_b"] = _f32(self.norm.weight).to(dev), _f32(self.norm.bias).to(dev)
+        pl["proj_in"] = ops.pack_weight(self.proj_in.weight.detach(), self.proj_in.bias.detach(), device=dev)
+        pl["proj_out"] = ops.pack_weight(self.proj_out.weight.detach(), self.proj_out.bias.detach(), device=dev)
+        for i, n in enumerate((tb.norm1, tb.norm2, tb.norm3)):
+            pl[f"ln{i + 1}_g"], pl[f"ln{i + 1}_b"] = _f32(n.weight).to(dev), _f32(n.bias).to(dev)
+        for name, attn in (("a1", tb.attn1), ("a2", tb.attn2)):
+            mask = attn.gate.hard_uniform()
+            compact = mask is not None and not bool((mask == 1).all())
+            if mask is not None and float(mask.sum()) == 0:
+                raise ValueError("head gate with no live head (the reference forbids it: non_zero_width)")
+            live = _live_index(mask, 64) if compact else None
+            hl = int(mask.sum()) if compact else attn.heads
+            pl[name + "_heads"], pl[name + "_compact"] = hl, compact
+            pl[name + "_dense_gate"] = mask is None
+            wq, wk, wv = (_f32(t.weight) for t in (attn.to_q, attn.to_k, attn.to_v))
+            if live is not None:
+                wq, wk, wv = wq[live], wk[live], wv[live]
+            if not attn.is_cross:
+                pl[name + "_qkv"] = ops.pack_weight(torch.cat([wq, wk, wv], 0), None, device=dev)
+            else:
+                pl[name + "_q"] = ops.pack_weight(wq, None, device=dev)
+                pl[name + "_kv_w"] = torch.cat([wk, wv], 0)          # batched across layers by the model
+            pl[name + "_o"] = ops.pack_weight(attn.to_out[0].weight.detach(), attn.to_out[0].bias.detach(),
+                                              in_idx=live, device=dev)
+        geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
+        mask = geglu.gate.hard_uniform()
+        compact = mask is not None and not bool((mask == 1).all())
+        if mask is not None and float(mask.sum()) == 0:
+            raise ValueError("FF gate with no live chunk (the reference forbids it: non_zero_width)")
+        chunk = geglu.dim_out // geglu.gate.width
+        live = _live_index(mask, chunk) if compact else None
+        pl["ff_compact"], pl["ff_dense_gate"] = compact, mask is None
+        pl["ff1"] = ops.pack_weight(geglu.proj.weight.detach(), geglu.proj.bias.detach(), out_idx=live, geglu=True, device=dev)
+        inner_pad = pl["ff1"].N // 2
+        pl["ff2"] = ops.pack_weight(lin2.weight.detach(), lin2.bias.detach(), in_idx=live, cin_pad_to=16, device=dev)
+        assert pl["ff2"].Cin == inner_pad, (pl["ff2"].Cin, inner_pad)
+        self._plans[key] = pl
+        return pl
+
+    def _depth_state(self):
+        return None, None
+
+    @staticmethod
+    def _gate(gate, dev, rep: int = 1):
+        g = gate.gate_f.detach().to(device=dev, dtype=torch.float32)
+        if rep > 1:
+            g = g.repeat(1, rep)
+        return g.contiguous()
+
+    # ---- forward --------------------------------------------------------------------------------------------------
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None,
+                class_labels=None, cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None,
+                return_dict: bool = True):
+        if attention_mask is not None or encoder_attention_mask is not None:
+            raise NotImplementedError("attention masks are not used on the APTP path (pruning_pipelines.py:796-802)")
+        x = _nhwc(hidden_states)
+        d_hard, d_vec = self._depth_state()
+        if self.depth_gated and (self.dropped or d_hard == 0.0):
+            return self._ret(hidden_states, return_dict)                  # blocks.py:1190-1194
+        dev = x.device
+        pl = self.plan(dev)
+        tb = self.transformer_blocks[0]
+        B, H, W, C = x.shape
+        P = H * W
+        a = ops.groupnorm(x, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False)
+        tok = a.reshape(B, P, C)
+        x_tok = x.reshape(B, P, C) if x.is_contiguous() else x.contiguous().reshape(B, P, C)
+        h = ops.linear(tok, pl["proj_in"])
+        # --- self attention
+        n = ops.layernorm(h, pl["ln1_g"], pl["ln1_b"], 1e-5)
+        hl = pl["a1_heads"]
+        gkw = {}
+        if pl["a1_dense_gate"]:
+            gkw = dict(colgate=self._gate(tb.attn1.gate, dev, 3), gate_group=64)
+        qkv = ops.linear(n, pl["a1_qkv"], **gkw)
+        w = hl * 64
+        o = ops.attention(qkv[..., :w], qkv[..., w:2 * w], qkv[..., 2 * w:3 * w], hl)
+        h = ops.linear(o, pl["a1_o"], residual=h)
+        # --- cross attention
+        n = ops.layernorm(h, pl["ln2_g"], pl["ln2_b"], 1e-5)
+        hl = pl["a2_heads"]
+        w = hl * 64
+        gkw = {}
+        if pl["a2_dense_gate"]:
+            gkw = dict(colgate=self._gate(tb.attn2.gate, dev), gate_group=64)
+        q = ops.linear(n, pl["a2_q"], **gkw)
+        kv = self._ctx_kv(encoder_hidden_states, pl, tb, dev)
+        o = ops.attention(q, kv[..., :w], kv[..., w:2 * w], hl)
+        h = ops.linear(o, pl["a2_o"], residual=h)
+        # --- feed-forward
+        n = ops.layernorm(h, pl["ln3_g"], pl["ln3_b"], 1e-5)
+        gkw = {}
+        if pl["ff_dense_gate"]:
+            geglu = tb.ff.net[0]
+            gkw = dict(colgate=self._gate(geglu.gate, dev), gate_group=geglu.dim_out // geglu.gate.width)
+        f = ops.linear(n, pl["ff1"], **gkw)
+        h = ops.linear(f, pl["ff2"], residual=h)
+        # --- proj_out + residual (+ depth lerp)
+        dkw = {}
+        if self.depth_gated and d_hard is None:
+            dkw = dict(depth=d_vec, depth_in=x_tok)
+        out = ops.linear(h, pl["proj_out"], residual=x_tok, **dkw)
+        return self._ret(_nchw(out.reshape(B, H, W, C)), return_dict)
+
+    @staticmethod
+    def _ret(t, return_dict):
+        if not return_dict:
+            return (t,)
+        return Transformer2DModelOutput(sample=t)
+
+    def _ctx_kv(self, ehs, pl, tb, dev):
+        if isinstance(ehs, CtxBundle):
+            kv = ehs.kv.get(id(tb.attn2))
+            if kv is not None:
+                return kv
+            ehs_t = ehs.ehs
+        else:
+            ehs_t = ehs.to(device=dev, dtype=torch.bfloat16)
+        pw = pl.get("a2_kv")
+        if pw is None:
+            pw = ops.pack_weight(pl["a2_kv_w"], None, device=dev)
+            pl["a2_kv"] = pw
+        gkw = {}
+        if pl["a2_dense_gate"]:
+            gkw = dict(colgate=self._gate(tb.attn2.gate, dev, 2), gate_group=64)
+        return ops.linear(ehs_t, pw, **gkw)
+
+
+class Transformer2DModelWidthDepthGated(Transformer2DModelWidthGated):
+    """blocks.py:1070-1438"""
+    depth_gated = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.depth_gate = DepthGate(1)
+
+    def _depth_state(self):
+        h = self.depth_gate.host_value().flatten()
+        if bool(((h == 0) | (h == 1)).all()) and bool((h == h[0]).all()):
+            return float(h[0]), None
+        return None, self.depth_gate.gate_f.detach().flatten().to(dtype=torch.float32)
+
+
+@dataclass
+class Transformer2DModelOutput:
+    sample: torch.Tensor
+
+
+@dataclass
+class UNet2DConditionOutput:
+    sample: torch.Tensor
+
+
+class Downsample2D(nn.Module):
+    """diffusers Downsample2D(use_conv=True, padding=1): conv 3x3 stride 2."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = Conv2dP(channels, channels, 3)
+        self._pw = None
+
+    def invalidate(self):
+        self._pw = None
+
+    def forward(self, hidden_states, scale: float = 1.0):
+        x = _nhwc(hidden_states)
+        if self._pw is None or self._pw.w.device != x.device:
+            self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
+        return _nchw(ops.conv_gemm(x, self._pw, stride=2, pad=1))
+
+
+class Upsample2D(nn.Module):
+    """diffusers Upsample2D(use_conv=True): nearest x2 then conv 3x3 — the upsample is folded into the conv's gather."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = Conv2dP(channels, channels, 3)
+        self._pw = None
+
+    def invalidate(self):
+        self._pw = None
+
+    def forward(self, hidden_states, output_size=None, scale: float = 1.0):
+        x = _nhwc(hidden_states)
+        if self._pw is None or self._pw.w.device != x.device:
+            self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
+        return _nchw(ops.conv_gemm(x, self._pw, ups=1))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# block containers (forwards follow diffusers CrossAttnDownBlock2D / DownBlock2D / UNetMidBlock2DCrossAttn /
+# CrossAttnUpBlock2D / UpBlock2D; gate placement follows blocks.py:1717-1807, 2554-2736, 2004-2243, 2419-2550)
+# ----------------------------------------------------------------------------------------------------------------
+class _GatedContainer(nn.Module):
+    has_cross_attention = True
+
+    def _init_common(self):
+        self.structure = {"width": [], "depth": []}
+        self.total_macs, self.prunable_macs = 0.0, 0.0
+
+    def get_gate_structure(self):
+        if len(self.structure["width"]) == 0:
+            structure = {"width": [], "depth": []}
+            for b in list(self.resnets) + list(self.attentions):
+                s = b.get_gate_structure()
+                structure["width"].append(s["width"])
+                structure["depth"].append(s["depth"])
+            self.structure = structure
+        return self.structure
+
+    def set_gate_structure(self, arch_vectors):
+        # resnets first, then attentions — the order of get_gate_structure (blocks.py:1833-1861)
+        width_vectors, depth_vectors = arch_vectors["width"], arch_vectors["depth"]
+        for b in list(self.resnets) + list(self.attentions):
+            s = b.get_gate_structure()
+            block_vectors = {"width": [], "depth": []}
+            for i in range(len(s["width"])):
+                assert s["width"][i] == width_vectors[0].shape[1]
+                block_vectors["width"].append(width_vectors.pop(0))
+            for i in range(len(s["depth"])):
+                if s["depth"][i] == 1:
+                    block_vectors["depth"].append(depth_vectors.pop(0))
+            b.set_gate_structure(block_vectors)
+
+
+def _make_resnet(cin, cout, temb, depth_gated, groups, eps, concat=False, skip_dim=None):
+    cls = ResnetBlock2DWidthDepthGated if depth_gated else ResnetBlock2DWidthGated
+    return cls(in_channels=cin, out_channels=cout, temb_channels=temb, groups=groups, eps=eps,
+               is_input_concatenated=concat, skip_connection_dim=skip_dim)
+
+
+def _make_attn(ch, heads, xdim, depth_gated, groups, gated_ff, ff_gate_width):
+    cls = Transformer2DModelWidthDepthGated if depth_gated else Transformer2DModelWidthGated
+    return cls(heads, ch // heads, in_channels=ch, cross_attention_dim=xdim, norm_num_groups=groups,
+               gated_ff=gated_ff, ff_gate_width=ff_gate_width)
+
+
+class CrossAttnDownBlock2DWidthHalfDepthGated(_GatedContainer):
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, num_attention_heads, cross_attention_dim,
+                 add_downsample, resnet_groups=32, resnet_eps=1e-5, gated_ff=True, ff_gate_width=32, with_attention=True):
+        super().__init__()
+        self.has_cross_attention = with_attention
+        resnets, attentions = [], []
+        for i in range(num_layers):
+            last = i == num_layers - 1
+            resnets.append(_make_resnet(in_channels if i == 0 else out_channels, out_channels, temb_channels, last,
+                                        resnet_groups, resnet_eps))
+            if with_attention:
+                attentions.append(_make_attn(out_channels, num_attention_heads, cross_attention_dim, last,
+                                             resnet_groups, gated_ff, ff_gate_width))
+        self.attentions = nn.ModuleList(attentions)
+        self.resnets = nn.ModuleList(resnets)
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+        self._init_common()
+
+    def forward(self, hidden_states, temb=None, encoder_hidden_states=None, attention_mask=None,
+                cross_attention_kwargs=None, encoder_attention_mask=None, scale: float = 1.0):
+        output_states = ()
+        for i, resnet in enumerate(self.resnets):
+            hidden_states = resnet(hidden_states, temb)
+            if self.has_cross_attention:
+                hidden_states = self.attentions[i](hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                                   return_dict=False)[0]
+            output_states = output_states + (hidden_states,)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                hidden_states = d(hidden_states)
+            output_states = output_states + (hidden_states,)
+        return hidden_states, output_states
+
+
+class DownBlock2DWidthHalfDepthGated(CrossAttnDownBlock2DWidthHalfDepthGated):
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, add_downsample, resnet_groups=32,
+                 resnet_eps=1e-5):
+        super().__init__(in_channels, out_channels, temb_channels, num_layers, 1, 0, add_downsample, resnet_groups,
+                         resnet_eps, with_attention=False)
+
+
+class UNetMidBlock2DCrossAttnWidthGated(_GatedContainer):
+    def __init__(self, in_channels, temb_channels, num_attention_heads, cross_attention_dim, resnet_groups=32,
+                 resnet_eps=1e-5, gated_ff=True, ff_gate_width=32):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            _make_resnet(in_channels, in_channels, temb_channels, False, resnet_groups, resnet_eps),
+            _make_resnet(in_channels, in_channels, temb_channels, False, resnet_groups, resnet_eps)])
+        self.attentions = nn.ModuleList([
+            _make_attn(in_channels, num_attention_heads, cross_attention_dim, False, resnet_groups, gated_ff,
+                       ff_gate_width)])
+        self._init_common()
+
+    def forward(self, hidden_states, temb=None, encoder_hidden_states=None, attention_mask=None,
+                cross_attention_kwargs=None, encoder_attention_mask=None):
+        hidden_states = self.resnets[0](hidden_states, temb)
+        for attn, resnet in zip(self.attentions, self.resnets[1:]):
+            hidden_states = attn(hidden_states, encoder_hidden_states=encoder_hidden_states, return_dict=False)[0]
+            hidden_states = resnet(hidden_states, temb)
+        return hidden_states
+
+
+class CrossAttnUpBlock2DWidthHalfDepthGated(_GatedContainer):
+    def __init__(self, in_channels, out_channels, prev_output_channel, temb_channels, num_layers, num_attention_heads,
+                 cross_attention_dim, add_upsample, resnet_groups=32, resnet_eps=1e-5, gated_ff=True, ff_gate_width=32,
+                 with_attention=True):
+        super().__init__()
+        self.has_cross_attention = with_attention
+        resnets, attentions = [], []
+        for i in range(num_layers):
+            last = i == num_layers - 1
+            res_skip = in_channels if last else out_channels
+            res_in = prev_output_channel if i == 0 else out_channels
+            resnets.append(_make_resnet(res_in + res_skip, out_channels, temb_channels, last, resnet_groups, resnet_eps,
+                                        concat=True, skip_dim=res_skip))
+            if with_attention:
+                attentions.append(_make_attn(out_channels, num_attention_heads, cross_attention_dim, last,
+                                             resnet_groups, gated_ff, ff_gate_width))
+        self.attentions = nn.ModuleList(attentions)
+        self.resnets = nn.ModuleList(resnets)
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+        self._init_common()
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None,
+                cross_attention_kwargs=None, upsample_size=None, attention_mask=None, encoder_attention_mask=None,
+                scale: float = 1.0):
+        for i, resnet in enumerate(self.resnets):
+            res_hidden_states = res_hidden_states_tuple[-1]
+            res_hidden_states_tuple = res_hidden_states_tuple[:-1]
+            hidden_states = _cat_channels(hidden_states, res_hidden_states)
+            hidden_states = resnet(hidden_states, temb)
+            if self.has_cross_attention:
+                hidden_states = self.attentions[i](hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                                   return_dict=False)[0]
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                hidden_states = u(hidden_states, upsample_size)
+        return hidden_states
+
+
+class UpBlock2DWidthHalfDepthGated(CrossAttnUpBlock2DWidthHalfDepthGated):
+    def __init__(self, in_channels, out_channels, prev_output_channel, temb_channels, num_layers, add_upsample,
+                 resnet_groups=32, resnet_eps=1e-5):
+        super().__init__(in_channels, out_channels, prev_output_channel, temb_channels, num_layers, 1, 0, add_upsample,
+                         resnet_groups, resnet_eps, with_attention=False)
+
+
+def _cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=1) for channels_last activations, produced directly in NHWC memory."""
+    A, Bn = _nhwc(a), _nhwc(b)
+    out = torch.empty(A.shape[0], A.shape[1], A.shape[2], A.shape[3] + Bn.shape[3], dtype=A.dtype, device=A.device)
+    out[..., :A.shape[3]].copy_(A)
+    out[..., A.shape[3]:].copy_(Bn)
+    return _nchw(out)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------------------------
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels: int, time_embed_dim: int):
+        super().__init__()
+        self.linear_1 = LinearP(in_channels, time_embed_dim)
+        self.linear_2 = LinearP(time_embed_dim, time_embed_dim)
+
+
+class UNet2DConditionModelGated(nn.Module):
+    """unet_2d_conditional.py:628-2181 for the SD-2.1 family of configurations."""
+
+    def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
+                 down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock2DWidthHalfDepthGated",) * 3 + ("DownBlock2DWidthHalfDepthGated",),
+                 mid_block_type: str = "UNetMidBlock2DCrossAttnWidthGated",
+                 up_block_types: Tuple[str, ...] = ("UpBlock2DWidthHalfDepthGated",) + ("CrossAttnUpBlock2DWidthHalfDepthGated",) * 3,
+                 block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280), layers_per_block: int = 2,
+                 cross_attention_dim: int = 1024, attention_head_dim: Union[int, Tuple[int, ...]] = (5, 10, 20, 20),
+                 norm_num_groups: int = 32, norm_eps: float = 1e-5, gated_ff: bool = True, ff_gate_width: int = 32,
+                 **unused):
+        super().__init__()
+        n = len(block_out_channels)
+        heads = (attention_head_dim,) * n if isinstance(attention_head_dim, int) else tuple(attention_head_dim)
+        assert len(down_block_types) == n and len(up_block_types) == n
+        self.config = dict(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+                           down_block_types=tuple(down_block_types), mid_block_type=mid_block_type,
+                           up_block_types=tuple(up_block_types), block_out_channels=tuple(block_out_channels),
+                           layers_per_block=layers_per_block, cross_attention_dim=cross_attention_dim,
+                           attention_head_dim=heads, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
+                           gated_ff=gated_ff, ff_gate_width=ff_gate_width)
+        boc = tuple(block_out_channels)
+        T = boc[0] * 4
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv_in = Conv2dP(in_channels, boc[0], 3)
+        self.time_embedding = TimestepEmbedding(boc[0], T)
+        self.down_blocks = nn.ModuleList()
+        out_ch = boc[0]
+        for i, t in enumerate(down_block_types):
+            in_ch, out_ch = out_ch, boc[i]
+            last = i == n - 1
+            if t == "CrossAttnDownBlock2DWidthHalfDepthGated":
+                blk = CrossAttnDownBlock2DWidthHalfDepthGated(in_ch, out_ch, T, layers_per_block, heads[i],
+                                                              cross_attention_dim, not last, norm_num_groups, norm_eps,
+                                                              gated_ff, ff_gate_width)
+            elif t == "DownBlock2DWidthHalfDepthGated":
+                blk = DownBlock2DWidthHalfDepthGated(in_ch, out_ch, T, layers_per_block, not last, norm_num_groups,
+                                                     norm_eps)
+            else:
+                raise ValueError(f"unsupported down block type {t}")
+            self.down_blocks.append(blk)
+        assert mid_block_type == "UNetMidBlock2DCrossAttnWidthGated"
+        self.mid_block = UNetMidBlock2DCrossAttnWidthGated(boc[-1], T, heads[-1], cross_attention_dim, norm_num_groups,
+                                                           norm_eps, gated_ff, ff_gate_width)
+        self.up_blocks = nn.ModuleList()
+        rev, rev_heads = list(reversed(boc)), list(reversed(heads))
+        out_ch = rev[0]
+        for i, t in enumerate(up_block_types):
+            prev_out, out_ch = out_ch, rev[i]
+            in_ch = rev[min(i + 1, n - 1)]
+            last = i == n - 1
+            if t == "CrossAttnUpBlock2DWidthHalfDepthGated":
+                blk = CrossAttnUpBlock2DWidthHalfDepthGated(in_ch, out_ch, prev_out, T, layers_per_block + 1,
+                                                            rev_heads[i], cross_attention_dim, not last,
+                                                            norm_num_groups, norm_eps, gated_ff, ff_gate_width)
+            elif t == "UpBlock2DWidthHalfDepthGated":
+                blk = UpBlock2DWidthHalfDepthGated(in_ch, out_ch, prev_out, T, layers_per_block + 1, not last,
+                                                   norm_num_groups, norm_eps)
+            else:
+                raise ValueError(f"unsupported up block type {t}")
+            self.up_blocks.append(blk)
+        self.conv_norm_out = NormP(boc[0], norm_eps, norm_num_groups)
+        self.conv_out = Conv2dP(boc[0], out_channels, 3)
+        self.structure = {"width": [], "depth": []}
+        self.prunable_macs_list = None
+        self.resource_info_dict = None
+        self.semantics = "gated"
+        self._misc = None       # packed conv_in / time MLP / conv_out
+        self._batched = {}      # structure-key -> batched temb / ctx-kv packs
+
+    # ---- construction helpers -------------------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config: Optional[dict] = None, **kwargs):
+        cfg = dict(config or {})
+        cfg.update(kwargs)
+        return cls(**cfg)
+
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 0, w_std: float = 0.02, beta_std: float = 0.1):
+        """Seeded random-init weights at the configured shapes (no checkpoint access on the GPU box): N(0, w_std)
+        conv/linear weights, N(0, w_std/2) biases, norm gamma = 1, norm beta ~ N(0, beta_std)."""
+        g = torch.Generator().manual_seed(seed)
+        for name, prm in self.named_parameters():
+            owner = self.get_submodule(name.rsplit(".", 1)[0])
+            if isinstance(owner, NormP):
+                if name.endswith(".weight"):
+                    prm.fill_(1.0)
+                else:
+                    prm.copy_(torch.randn(prm.shape, generator=g) * beta_std)
+            elif name.endswith(".weight"):
+                prm.copy_(torch.randn(prm.shape, generator=g) * w_std)
+            else:
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.5 * w_std))
+        self.invalidate_plans()
+        return self
+
+    def invalidate_plans(self):
+        """Drop every packed-weight cache (call after changing parameters)."""
+        self._misc = None
+        self._batched = {}
+        for m in self.modules():
+            if m is not self and hasattr(m, "invalidate"):
+                m.invalidate()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_plans()
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_plans()
+        return out
+
+    # ---- reference API --------------------------------------------------------------------------------------------
+    def freeze(self):
+        # unet_2d_conditional.py:2118-2122: gate_f is a plain attribute, so this freezes every parameter (quirk Q2)
+        for name, param in self.named_parameters():
+            if "gate_f" not in name:
+                param.requires_grad = False
+
+    def _containers(self):
+        return list(self.down_blocks) + [self.mid_block] + list(self.up_blocks)
+
+    def get_structure(self):
+        if len(self.structure["width"]) == 0:
+            structure = {"width": [], "depth": []}
+            for m in self._containers():
+                s = m.get_gate_structure()
+                assert len(s) == 2 and len(s["width"]) == len(s["depth"])
+                structure["width"] = structure["width"] + s["width"]
+                structure["depth"] = structure["depth"] + s["depth"]
+            self.structure = structure
+        return self.structure
+
+    def set_structure(self, arch_vectors):
+        """unet_2d_conditional.py:1365-1413 — consumes (pops) the caller's width/depth lists."""
+        width_vectors, depth_vectors = arch_vectors["width"], arch_vectors["depth"]
+        # one bulk device->host copy of all gates so per-module mode selection needs no further syncs
+        self._prefetch_hosts(width_vectors, depth_vectors)
+        for m in self._containers():
+            s = m.get_gate_structure()
+            block_vectors = {"width": [], "depth": []}
+            for i in range(len(s["width"])):
+                for j in range(len(s["width"][i])):
+                    assert s["width"][i][j] == width_vectors[0].shape[1]
+                    block_vectors["width"].append(width_vectors.pop(0))
+            for i in range(len(s["depth"])):
+                if s["depth"][i] == [1]:
+                    block_vectors["depth"].append(depth_vectors.pop(0))
+            m.set_gate_structure(block_vectors)
+        self._attach_hosts()
+
+    def _prefetch_hosts(self, width_vectors, depth_vectors):
+        self._host_map = {}
+        tensors = list(width_vectors) + list(depth_vectors)
+        if not tensors:
+            return
+        if all(t.device.type == "cpu" for t in tensors):
+            return
+        flat = torch.cat([t.detach().float().reshape(-1) for t in tensors]).cpu()
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            self._host_map[id(t)] = flat[off:off + n].reshape(t.shape)
+            off += n
+
+    def _attach_hosts(self):
+        hm = getattr(self, "_host_map", None)
+        if not hm:
+            return
+        for m in self.modules():
+            if isinstance(m, (WidthGate, DepthGate)):
+                h = hm.get(id(m.gate_f))
+                if h is not None:
+                    m.set_host_value(h)
+        self._host_map = {}
+
+    # ---- model-level packed weights ---------------------------------------------------------------------------------
+    def _resnets(self):
+        return [m for m in self.modules() if isinstance(m, ResnetBlock2DWidthGated)]
+
+    def _transformers(self):
+        return [m for m in self.modules() if isinstance(m, Transformer2DModelWidthGated)]
+
+    def _misc_packs(self, dev):
+        if self._misc is None or self._misc["dev"] != str(dev):
+            cin_pad = ops.round_up(self.in_channels, 8)
+            m = {"dev": str(dev), "cin_pad": cin_pad}
+            m["conv_in"] = ops.pack_weight(self.conv_in.weight.detach(), self.conv_in.bias.detach(), device=dev)
+            te = self.time_embedding
+            m["t1"] = ops.pack_weight(te.linear_1.weight.detach(), te.linear_1.bias.detach(), device=dev)
+            m["t2"] = ops.pack_weight(te.linear_2.weight.detach(), te.linear_2.bias.detach(), device=dev)
+            m["gn_g"], m["gn_b"] = _f32(self.conv_norm_out.weight).to(dev), _f32(self.conv_norm_out.bias).to(dev)
+            m["conv_out"] = ops.pack_weight(self.conv_out.weight.detach(), self.conv_out.bias.detach(), device=dev)
+            half = self.conv_in.out_channels // 2
+            m["freqs"] = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=dev) / half)
+            self._misc = m
+        return self._misc
+
+    def _batched_packs(self, dev):
+        """One GEMM for all 22 time_emb_proj, one for all 16 cross-attention K/V projections."""
+        resnets, trans = self._resnets(), self._transformers()
+        for r in resnets:
+            r.semantics = self.semantics
+        rplans = [r.plan(dev) for r in resnets if not (r.depth_gated and (r.dropped or r._depth_state()[0] == 0.0))]
+        live_res = [r for r in resnets if not (r.depth_gated and (r.dropped or r._depth_state()[0] == 0.0))]
+        live_tr = [t for t in trans if not (t.depth_gated and (t.dropped or t._depth_state()[0] == 0.0))]
+        tplans = [t.plan(dev) for t in live_tr]
+        key = (tuple(id(p) for p in rplans), tuple(id(p) for p in tplans), str(dev))
+        bp = self._batched.get(key)
+        if bp is not None:
+            return bp
+        if len(self._batched) >= 4:
+            self._batched.pop(next(iter(self._batched)))
+        bp = {"key": key}
+        ws, bs, slots, off = [], [], [], 0
+        for r, pl in zip(live_res, rplans):
+            npad = pl["c_pad"]
+            w, b = pl["temb_w"], pl["temb_b"]
+            if w.shape[0] != npad:
+                w = torch.cat([w, w.new_zeros(npad - w.shape[0], w.shape[1])], 0)
+                b = torch.cat([b, b.new_zeros(npad - b.shape[0])], 0)
+            ws.append(w); bs.append(b)
+            slots.append((id(r), off, npad))
+            off += npad
+        bp["temb_pw"] = ops.pack_weight(torch.cat(ws, 0), torch.cat(bs, 0), device=dev)
+        bp["temb_slots"] = slots
+        ws, slots, off, gates = [], [], 0, []
+        for t, pl in zip(live_tr, tplans):
+            w = pl["a2_kv_w"]
+            ws.append(w)
+            slots.append((id(t.transformer_blocks[0].attn2), off, w.shape[0]))
+            off += w.shape[0]
+            gates.append((t.transformer_blocks[0].attn2.gate, pl["a2_dense_gate"], pl["a2_heads"]))
+        if ws:
+            bp["kv_pw"] = ops.pack_weight(torch.cat(ws, 0), None, device=dev)
+        bp["kv_slots"] = slots
+        bp["kv_gates"] = gates
+        self._batched[key] = bp
+        return bp
+
+    # ---- forward (unet_2d_conditional.py:1415-1726) -------------------------------------------------------------------
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None,
+                return_dict: bool = True):
+        # no CPU path exists: ops.* reject non-CUDA tensors and _lib.load() raises if libaptp_hip.so is missing
+        if attention_mask is not None or encoder_attention_mask is not None or class_labels is not None \
+                or down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("only the arguments the APTP trainer/pipeline pass are supported")
+        dev = sample.device
+        B = sample.shape[0]
+        misc = self._misc_packs(dev)
+        bp = self._batched_packs(dev)
+        out_dtype = sample.dtype
+
+        # 1. time (unet_2d_conditional.py:1497-1519): sinusoid [cos|sin] -> Linear -> SiLU -> Linear; the SiLU that
+        # every resnet applies to emb (blocks.py:335) is fused into linear_2's epilogue.
+        timesteps = timestep
+        if not torch.is_tensor(timesteps):
+            timesteps = torch.tensor([timesteps], dtype=torch.int64, device=dev)
+        elif timesteps.dim() == 0:
+            timesteps = timesteps[None].to(dev)
+        timesteps = timesteps.to(dev).expand(B)
+        ang = timesteps.float()[:, None] * misc["freqs"][None, :]
+        t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
+        e1 = ops.linear(t_emb[None], misc["t1"], act=ops.ACT_SILU)
+        emb_silu = ops.linear(e1, misc["t2"], act=ops.ACT_SILU)           # bf16 [1, B, T] = SiLU(emb)
+        tproj = ops.linear(emb_silu, bp["temb_pw"], out_f32=True)[0]      # fp32 [B, sum Npad]
+        temb = TembBundle(emb_silu=emb_silu[0])
+        for rid, off, npad in bp["temb_slots"]:
+            temb.proj[rid] = tproj[:, off:off + npad]
+
+        # text states: one batched K/V projection for all cross-attention layers
+        ehs = encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous()
+        ctx = CtxBundle(ehs=ehs)
+        if bp["kv_slots"]:
+            gkw = {}
+            if any(dense for (_, dense, _) in bp["kv_gates"]):
+                cols = []
+                for gate, dense, hl in bp["kv_gates"]:
+                    g = gate.gate_f.detach().to(device=dev, dtype=torch.float32) if dense else None
+                    bg = max(gt.gate_f.shape[0] for gt, d_, _ in bp["kv_gates"] if d_)
+                    if g is None:
+                        g = torch.ones(bg, hl, device=dev)
+                    elif g.shape[0] != bg:
+                        g = g.repeat(bg // g.shape[0], 1)
+                    cols.append(g.repeat(1, 2))
+                gkw = dict(colgate=torch.cat(cols, 1).contiguous(), gate_group=64)
+            kv_all = ops.linear(ehs, bp["kv_pw"], **gkw)
+            for aid, off, n in bp["kv_slots"]:
+                ctx.kv[aid] = kv_all[..., off:off + n]
+
+        # 2. pre-process: conv_in on the channel-padded NHWC input
+        x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
+        x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
+        h = _nchw(ops.conv_gemm(x, misc["conv_in"]))
+
+        # 3. down
+        down_block_res_samples = (h,)
+        for blk in self.down_blocks:
+            h, res = blk(hidden_states=h, temb=temb, encoder_hidden_states=ctx)
+            down_block_res_samples += res
+        # 4. mid
+        h = self.mid_block(h, temb, encoder_hidden_states=ctx)
+        # 5. up
+        for blk in self.up_blocks:
+            n_res = len(blk.resnets)
+            res = down_block_res_samples[-n_res:]
+            down_block_res_samples = down_block_res_samples[:-n_res]
+            h = blk(hidden_states=h, temb=temb, res_hidden_states_tuple=res, encoder_hidden_states=ctx)
+        # 6. post-process
+        a = ops.groupnorm(_nhwc(h), misc["gn_g"], misc["gn_b"], self.conv_norm_out.num_groups, self.conv_norm_out.eps, True)
+        y = ops.conv_gemm(a, misc["conv_out"], out_f32=True)                # fp32 [B,H,W,roundup8(out)]
+        out = y[..., :self.out_channels].permute(0, 3, 1, 2).to(out_dtype)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+
+class UNet2DConditionModelPruned(UNet2DConditionModelGated):
+    """unet_2d_conditional.py:2184-2472: the physically pruned expert.  Same kernels; hard masks compact the weights
+    and — unlike the gated model — dead GroupNorm channels are deleted, not kept at beta (blocks.py:451-463), so no
+    beta correction is applied; depth-0 blocks are dropped (blocks.py:645-658, 1432-1438)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.semantics = "pruned"
+
+    def prune(self, arch_vectors):
+        """Binarise the architecture code with hard_concrete's threshold (estimation_utils.py:67-75), install it and
+        mark modules pruned / dropped — what the reference does inside from_pretrained (:2421-2436) through the
+        per-module prune() methods (which require a single-row gate, blocks.py:426)."""
+        hard = {"width": [(w.detach() >= 0.5).float() for w in arch_vectors["width"]],
+                "depth": [(d.detach() >= 0.5).float() for d in arch_vectors["depth"]]}
+        for t in hard["width"] + hard["depth"]:
+            assert t.shape[0] == 1, "Pruning is only supported for single batch size"
+        self.set_structure(hard)
+        for r in self._resnets():
+            r.pruned = True
+            r.dropped = bool(r.depth_gated and r._depth_state()[0] == 0.0)
+        for t in self._transformers():
+            t.pruned = True
+            t.dropped = bool(t.depth_gated and t._depth_state()[0] == 0.0)
+        return self

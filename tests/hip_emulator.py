@@ -1,0 +1,104 @@
+"""TEST-ONLY stand-in for diffusion_pruning_amd.ops, written in plain PyTorch fp32 on CPU.
+
+Purpose: exercise the *host logic* of the product (weight packing/compaction, GEGLU interleave, batched temb/KV GEMMs,
+GroupNorm-beta border correction, gate plumbing, skip-concat handling) in the `-m "not gpu"` suite, where no GPU
+exists.  It consumes the very PackedWeight objects the product builds and re-implements the documented semantics of
+include/aptp_hip.h.  It is never imported by the package; on a GPU the real kernels run (tests/test_unet_gpu.py).
+"""
+import torch
+import torch.nn.functional as F
+
+from diffusion_pruning_amd import ops as real_ops
+from diffusion_pruning_amd._lib import ACT_GEGLU, ACT_NONE, ACT_SILU
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colgate=None, gate_group=0, act=ACT_NONE,
+              corr=None, residual=None, depth=None, depth_in=None, out_f32=False, split_k=None, tile=0):
+    B, H, W, C = x.shape
+    assert C == pw.Cin and x.dtype == torch.bfloat16
+    if pad is None:
+        pad = pw.KH // 2
+    if pw.geglu:
+        act = ACT_GEGLU
+    w = pw.w.float()[:, :, :C].reshape(pw.N, pw.KH, pw.KW, C).permute(0, 3, 1, 2)
+    xin = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xin, w, pw.bias, stride=stride, padding=pad)
+    if rowbias is not None:
+        y = y + rowbias[:, :pw.N, None, None]
+    Ho, Wo = y.shape[2:]
+    if act == ACT_GEGLU:
+        y = y.reshape(B, pw.N // 32, 2, 16, Ho, Wo)
+        h, g = y[:, :, 0].reshape(B, pw.N // 2, Ho, Wo), y[:, :, 1].reshape(B, pw.N // 2, Ho, Wo)
+        if colgate is not None:
+            m = colgate.repeat_interleave(gate_group, dim=1).repeat(B // colgate.shape[0], 1)[:, :, None, None]
+            h, g = h * m, g * m
+        y = h * F.gelu(g)
+    else:
+        if colgate is not None:
+            m = colgate.repeat_interleave(gate_group, dim=1).repeat(B // colgate.shape[0], 1)[:, :, None, None]
+            y = y * m
+        if act == ACT_SILU:
+            y = F.silu(y)
+    if corr is not None:
+        cr = torch.ones(Ho, dtype=torch.long); cr[0] = 0; cr[-1] = 2
+        cc = torch.ones(Wo, dtype=torch.long); cc[0] = 0; cc[-1] = 2
+        cmap = cr[:, None] * 3 + cc[None, :]
+        add = corr[:, cmap]                       # [cB, Ho, Wo, N]
+        y = y + add.permute(0, 3, 1, 2).repeat(B // corr.shape[0], 1, 1, 1)
+    if residual is not None:
+        y = y + residual.float().permute(0, 3, 1, 2)
+    if depth is not None:
+        d = depth.repeat(B // depth.shape[0])[:, None, None, None]
+        y = (1 - d) * depth_in.float().permute(0, 3, 1, 2) + d * y
+    y = y.permute(0, 2, 3, 1)
+    y = y.contiguous() if out_f32 else _bf(y).contiguous()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def linear(x, pw, **kw):
+    out = kw.pop("out", None)
+    for k in ("residual", "depth_in"):
+        if kw.get(k) is not None:
+            kw[k] = kw[k].unsqueeze(2)
+    y = conv_gemm(x.unsqueeze(2), pw, pad=0, out=None if out is None else out.unsqueeze(2), **kw)
+    return y.squeeze(2)
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu, C=None, out=None):
+    B, H, W, Cp = x.shape
+    C = Cp if C is None else C
+    y = F.group_norm(x.float()[..., :C].permute(0, 3, 1, 2), groups, gamma, beta, eps)
+    if silu:
+        y = F.silu(y)
+    res = torch.zeros(B, H, W, Cp, dtype=torch.bfloat16)
+    res[..., :C] = _bf(y.permute(0, 2, 3, 1))
+    return res
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    return _bf(F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps))
+
+
+def attention(q, k, v, heads, scale=None, out=None):
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+
+    def hd(t, L):
+        return t.float().reshape(B, L, heads, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(hd(q, Lq), hd(k, Lk), hd(v, Lk))
+    return _bf(o.transpose(1, 2).reshape(B, Lq, heads * 64))
+
+
+def install(monkeypatch):
+    """Route the product's ops.* calls to this emulator for the duration of a test."""
+    for name in ("conv_gemm", "linear", "groupnorm", "layernorm", "attention"):
+        monkeypatch.setattr(real_ops, name, globals()[name])

@@ -1,0 +1,124 @@
+"""CPU tests of the product's host logic (no GPU): the model code runs unchanged, with the HIP ops replaced by the
+test-only PyTorch emulator (tests/hip_emulator.py), and must agree with the oracle."""
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from tests import hip_emulator
+
+TOL = 2e-2
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def clone_mask(m):
+    return {k: [v.clone() for v in vs] for k, vs in m.items()}
+
+
+@pytest.fixture()
+def tiny(monkeypatch):
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    hip_emulator.install(monkeypatch)
+    cfg = O.TINY
+    model = UNet2DConditionModelGated(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
+                                      cross_attention_dim=cfg.cross_attention_dim).init_synthetic(seed=0)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return cfg, model, params
+
+
+def run(model, mask, sample, t, ehs):
+    model.set_structure(clone_mask(mask))
+    with torch.no_grad():
+        return model(sample, t, ehs).sample.float()
+
+
+def test_state_dict_matches_diffusers_names_and_sd21_param_count():
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    m = UNet2DConditionModelGated()
+    sd = m.state_dict()
+    shapes = O.param_shapes(O.SD21)
+    assert set(sd) == set(shapes)
+    assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    assert sum(p.numel() for p in m.parameters()) == 865_910_724
+    st = m.get_structure()
+    assert st == O.get_structure(O.SD21)
+    assert sum(len(s) for s in st["width"]) == 70 and sum(d for s in st["depth"] for d in s) == 14
+    mask = O.fixed_half_mask(O.SD21)
+    m.set_structure(mask)
+    assert mask["width"] == [] and mask["depth"] == []      # set_structure consumes the caller's lists
+
+
+def test_dense(tiny):
+    cfg, model, params = tiny
+    sample, t, ehs = O.synthetic_inputs(cfg, 2, 16)
+    ref = O.unet_forward(params, cfg, sample, t, ehs)
+    assert rel_l2(run(model, O.ones_mask(cfg), sample, t, ehs), ref) <= TOL
+
+
+def test_half_mask_matches_gated_not_pruned(tiny):
+    cfg, model, params = tiny
+    sample, t, ehs = O.synthetic_inputs(cfg, 2, 16)
+    mask = O.fixed_half_mask(cfg)
+    ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
+    refp = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "pruned")
+    out = run(model, mask, sample, t, ehs)
+    e, ep = rel_l2(out, ref), rel_l2(out, refp)
+    assert e <= TOL and ep > 2 * e, (e, ep)
+
+
+@pytest.mark.parametrize("seed,keep,ndoff", [(1, 0.4, 2), (2, 0.75, 4)])
+def test_random_masks_with_depth(tiny, seed, keep, ndoff):
+    cfg, model, params = tiny
+    sample, t, ehs = O.synthetic_inputs(cfg, 2, 16, seed=seed)
+    mask = O.random_mask(cfg, keep, seed, n_depth_off=ndoff)
+    ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
+    assert rel_l2(run(model, mask, sample, t, ehs), ref) <= TOL
+
+
+def test_soft_per_sample_cfg(tiny):
+    cfg, model, params = tiny
+    sample, t, ehs = O.synthetic_inputs(cfg, 4, 16, seed=9)
+    g = torch.Generator().manual_seed(4)
+    st = O.get_structure(cfg)
+    mask = {"width": [torch.rand(2, w, generator=g) * 0.9 + 0.1 for sub in st["width"] for w in sub],
+            "depth": [torch.rand(2, generator=g) for sub in st["depth"] for d in sub if d == 1]}
+    ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
+    assert rel_l2(run(model, mask, sample, t, ehs), ref) <= TOL
+
+
+def test_hard_per_sample(tiny):
+    cfg, model, params = tiny
+    sample, t, ehs = O.synthetic_inputs(cfg, 2, 16, seed=5)
+    mask = O.random_mask(cfg, 0.5, 7, n_depth_off=1, batch=2)
+    mask["depth"][0] = torch.tensor([1.0, 0.0])
+    ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
+    assert rel_l2(run(model, mask, sample, t, ehs), ref) <= TOL
+
+
+def test_pruned_semantics(tiny, monkeypatch):
+    from diffusion_pruning_amd.unet import UNet2DConditionModelPruned
+    cfg, model, params = tiny
+    pm = UNet2DConditionModelPruned(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
+                                    cross_attention_dim=cfg.cross_attention_dim)
+    pm.load_state_dict(params)
+    mask = O.random_mask(cfg, 0.5, 11, n_depth_off=2)
+    soft = {"width": [w * 0.9 for w in mask["width"]], "depth": [d * 0.9 for d in mask["depth"]]}
+    pm.prune(clone_mask(soft))
+    sample, t, ehs = O.synthetic_inputs(cfg, 2, 16, seed=6)
+    ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(soft)), "pruned")
+    with torch.no_grad():
+        out = pm(sample, t, ehs, return_dict=False)[0]
+    assert rel_l2(out.float(), ref) <= TOL
+
+
+def test_product_rejects_cpu_tensors_without_the_emulator():
+    """no CPU fallback: with the real ops, a CPU forward must fail loudly"""
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    cfg = O.TINY
+    model = UNet2DConditionModelGated(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
+                                      cross_attention_dim=cfg.cross_attention_dim).init_synthetic(seed=0)
+    sample, t, ehs = O.synthetic_inputs(cfg, 1, 16)
+    with pytest.raises(Exception):
+        model(sample, t, ehs)

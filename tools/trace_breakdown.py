@@ -1,0 +1,50 @@
+"""Per-forward kernel breakdown from a rocprofv3 --kernel-trace CSV: finds the periodic tail of the trace (the timed
+HIP-graph replays), and prints count / total / avg per kernel name for ONE period, plus inter-kernel gap time."""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"void ", "", n)
+    m = re.match(r"at::native::(\w+)<.*?(\w+_kernel_cuda|FillFunctor|CatArray\w+|silu_kernel|\w+Functor)", n)
+    if n.startswith("at::native"):
+        return "torch:" + (m.group(1) + ":" + m.group(2) if m else n[12:60])
+    return n.split("(")[0][:70]
+
+
+def main(path, skip_tail=0):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if skip_tail:
+        rows = rows[:-skip_tail]
+    names = [r["Kernel_Name"] for r in rows]
+    n = len(names)
+    best = None
+    for p in range(50, min(3000, n // 3)):
+        if names[n - p:] == names[n - 2 * p:n - p] == names[n - 3 * p:n - 2 * p]:
+            best = p
+            break
+    if best is None:
+        print("no periodic tail found")
+        return
+    p = best
+    seg = rows[n - 2 * p:n - p]
+    t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
+    agg = defaultdict(lambda: [0, 0])
+    busy = 0
+    for r in seg:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += d
+        busy += d
+    print(f"period = {p} kernels, wall {(t1 - t0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, gaps {(t1 - t0 - busy) / 1e6:.3f} ms")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{t / 1e3:9.1f} us  {c:4d} x {t / c / 1e3:7.2f} us  {k}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -34,18 +34,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
     for (int e = 0; e < 8; ++e) { s[pg][e] = 0.f; ss[pg][e] = 0.f; }
   if (active) {
     const __bf16* base = p.x + ((int64_t)b * p.HW) * p.ldx;
-    for (int r = r0 + rl; r < r1; r += p.RPAR) {
+    constexpr int U = 4;   // rows in flight per thread: the loop is latency-bound without it
+    for (int r = r0 + rl; r < r1; r += p.RPAR * U) {
+      uint4 q[U][NP];
 #pragma unroll
-      for (int pg = 0; pg < NP; ++pg) {
-        const int o = ot + pg * 256;
-        if (o < p.CO) {
-          const uint4 q = *reinterpret_cast<const uint4*>(base + (int64_t)r * p.ldx + o * 8);
+      for (int u = 0; u < U; ++u) {
+        const int rr = r + u * p.RPAR;
+#pragma unroll
+        for (int pg = 0; pg < NP; ++pg) {
+          const int o = ot + pg * 256;
+          q[u][pg] = make_uint4(0u, 0u, 0u, 0u);
+          if (rr < r1 && o < p.CO) q[u][pg] = *reinterpret_cast<const uint4*>(base + (int64_t)rr * p.ldx + o * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int pg = 0; pg < NP; ++pg) {
           float f[8];
-          unpack_bf16x8(q, f);
+          unpack_bf16x8(q[u][pg], f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { s[pg][e] += f[e]; ss[pg][e] += f[e] * f[e]; }
         }
-      }
     }
   }
   // per-channel partials -> LDS [rl][channel]
@@ -68,12 +78,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
   const int g = tid >> 3, sub = tid & 7;
   float a = 0.f, a2 = 0.f;
   if (g < p.G) {
-    const int n = p.cg * p.RPAR;
-    for (int i = sub; i < n; i += 8) {
-      const int rr = i / p.cg, c = g * p.cg + (i - rr * p.cg);
-      a += red[0][rr * CP + c];
-      a2 += red[1][rr * CP + c];
-    }
+    for (int rr = 0; rr < p.RPAR; ++rr)
+      for (int i = sub; i < p.cg; i += 8) {
+        const int c = g * p.cg + i;
+        a += red[0][rr * CP + c];
+        a2 += red[1][rr * CP + c];
+      }
   }
 #pragma unroll
   for (int off = 4; off >= 1; off >>= 1) {
@@ -92,16 +102,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
   __shared__ float mean_s[32], rstd_s[32];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
-  if (tid < p.G) {
+  {
+    // fold the stage-1 partials: 8 threads per group, fixed order => deterministic
+    const int g = tid >> 3, sub = tid & 7;
     float a = 0.f, a2 = 0.f;
-    const float* w = p.ws + ((int64_t)b * p.nchunk * p.G + tid) * 2;
-    for (int c = 0; c < p.nchunk; ++c) { a += w[(int64_t)c * p.G * 2]; a2 += w[(int64_t)c * p.G * 2 + 1]; }
-    const float inv = 1.0f / ((float)p.cg * (float)p.HW);
-    const float mean = a * inv;
-    float var = a2 * inv - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    mean_s[tid] = mean;
-    rstd_s[tid] = rsqrtf(var + p.eps);
+    if (g < p.G) {
+      const float* w = p.ws + ((int64_t)b * p.nchunk * p.G + g) * 2;
+      for (int c = sub; c < p.nchunk; c += 8) { a += w[(int64_t)c * p.G * 2]; a2 += w[(int64_t)c * p.G * 2 + 1]; }
+    }
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {
+      a += __shfl_xor(a, off);
+      a2 += __shfl_xor(a2, off);
+    }
+    if (g < p.G && sub == 0) {
+      const float inv = 1.0f / ((float)p.cg * (float)p.HW);
+      const float mean = a * inv;
+      float var = a2 * inv - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      mean_s[g] = mean;
+      rstd_s[g] = rsqrtf(var + p.eps);
+    }
   }
   __syncthreads();
   const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
@@ -112,11 +133,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
   for (int pg = 0; pg < NP; ++pg) {
     const int o = ot + pg * 256;
     valid[pg] = 0u;
+    const int c0 = o * 8;
+    int g = c0 / p.cg, rem = c0 - g * p.cg;   // one division per octet, then walk
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = o * 8 + e;
+      const int c = c0 + e;
       if (o < p.CO && c < p.C) {
-        const int g = c / p.cg;
         const float k = rstd_s[g] * p.gamma[c];
         sc[pg][e] = k;
         sh[pg][e] = p.beta[c] - mean_s[g] * k;
@@ -124,27 +146,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
       } else {
         sc[pg][e] = 0.f; sh[pg][e] = 0.f;
       }
+      if (++rem == p.cg) { rem = 0; ++g; }
     }
   }
   const int r0 = (int)(((int64_t)p.HW * chunk) / gridDim.x), r1 = (int)(((int64_t)p.HW * (chunk + 1)) / gridDim.x);
   const __bf16* xb = p.x + ((int64_t)b * p.HW) * p.ldx;
   __bf16* yb = p.y + ((int64_t)b * p.HW) * p.ldy;
-  for (int r = r0 + rl; r < r1; r += p.RPAR) {
+  constexpr int U = 2;
+  for (int r = r0 + rl; r < r1; r += p.RPAR * U) {
+    uint4 q[U][NP];
 #pragma unroll
-    for (int pg = 0; pg < NP; ++pg) {
-      const int o = ot + pg * 256;
-      if (o < p.CO) {
-        const uint4 q = *reinterpret_cast<const uint4*>(xb + (int64_t)r * p.ldx + o * 8);
-        float f[8];
-        unpack_bf16x8(q, f);
+    for (int u = 0; u < U; ++u) {
+      const int rr = r + u * p.RPAR;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float v = f[e] * sc[pg][e] + sh[pg][e];
-          if (p.silu) v = silu_f(v);
-          // channels >= C inside the last octet are padding: always written as exact zero
-          f[e] = ((valid[pg] >> e) & 1u) ? v : 0.f;
+      for (int pg = 0; pg < NP; ++pg) {
+        const int o = ot + pg * 256;
+        q[u][pg] = make_uint4(0u, 0u, 0u, 0u);
+        if (rr < r1 && o < p.CO) q[u][pg] = *reinterpret_cast<const uint4*>(xb + (int64_t)rr * p.ldx + o * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = r + u * p.RPAR;
+#pragma unroll
+      for (int pg = 0; pg < NP; ++pg) {
+        const int o = ot + pg * 256;
+        if (rr < r1 && o < p.CO) {
+          float f[8];
+          unpack_bf16x8(q[u][pg], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = f[e] * sc[pg][e] + sh[pg][e];
+            if (p.silu) v = silu_f(v);
+            // channels >= C inside the last octet are padding: always written as exact zero
+            f[e] = ((valid[pg] >> e) & 1u) ? v : 0.f;
+          }
+          *reinterpret_cast<uint4*>(yb + (int64_t)rr * p.ldy + o * 8) = pack_bf16x8(f);
         }
-        *reinterpret_cast<uint4*>(yb + (int64_t)r * p.ldy + o * 8) = pack_bf16x8(f);
       }
     }
   }
@@ -214,9 +252,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnK p) {
 }  // namespace
 
 extern "C" int aptp_groupnorm_nchunk(int HW) {
-  int n = HW / 64;
+  int n = HW / 16;   // >= 16 rows per stage-1 workgroup
   if (n < 1) n = 1;
-  if (n > 32) n = 32;
+  if (n > 128) n = 128;
   return n;
 }
 
@@ -242,9 +280,9 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   k.RPAR = 256 / k.TPR;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid1(k.nchunk, p->B);
-  int nchunk2 = p->HW / 16;   // ~16+ rows per apply block
+  int nchunk2 = p->HW / 16;   // >= 16 rows per apply workgroup
   if (nchunk2 < 1) nchunk2 = 1;
-  if (nchunk2 > 256) nchunk2 = 256;
+  if (nchunk2 > 128) nchunk2 = 128;
   dim3 grid2(nchunk2, p->B);
   if (CO <= 256) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);

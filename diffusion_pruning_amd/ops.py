@@ -138,6 +138,24 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out_idx
 
 _ws_cache = {}
 
+def tuning_key(M, N, Cin, taps, stride, ups, geglu) -> str:
+    return f"M{M}_N{N}_C{Cin}_T{taps}_s{stride}u{ups}g{int(bool(geglu))}"
+
+
+def _load_tuning():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
+# (tile, split_k) per GEMM shape measured on MI355X by tools/tune_convs.py; shapes not in the table fall back to the
+# library heuristic (aptp_conv_gemm_suggest_split_k / pick_tile).
+TUNING = _load_tuning()
+
 # Optional launch recorder used by bench.py's roofline leg: when a list, every aptp_conv_gemm launch appends
 # {"params": ConvGemmParams, "flops": algorithmic FLOPs, "keep": tensors referenced by the params}.
 LAUNCH_LOG = None
@@ -212,6 +230,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.y, p.ldy, p.out_f32 = out.data_ptr(), _ld(out), int(out_f32)
     p.tile = tile
     p.split_k = 1
+    if split_k is None and tile == 0:
+        tuned = TUNING.get(tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU))
+        if tuned is not None:
+            p.tile, split_k = tuned["tile"], tuned["split_k"]
     if split_k is None:
         split_k = lib.aptp_conv_gemm_suggest_split_k(ctypes.byref(p))
     p.split_k = max(1, int(split_k))

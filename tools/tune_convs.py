@@ -1,0 +1,125 @@
+"""Autotune (tile, split_k) of aptp_conv_gemm for every distinct launch of the SD-2.1 forward (masked and dense, bs=4),
+timed on the GPU with HIP-graph replays.  Writes diffusion_pruning_amd/tuning_gfx950.json (merged with the existing
+table) and gpurun_out/tune_convs.txt (per-launch table sorted by time).
+Usage: python tools/tune_convs.py [--dense] [--batch 4] [--quick]"""
+import argparse
+import copy
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import fixed_half_mask, ones_mask  # noqa: E402
+from diffusion_pruning_amd import ops  # noqa: E402
+from diffusion_pruning_amd._lib import ACT_GEGLU, ConvGemmParams  # noqa: E402
+from diffusion_pruning_amd.unet import UNet2DConditionModelGated  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def clone_params(p):
+    q = ConvGemmParams()
+    ctypes.memmove(ctypes.byref(q), ctypes.byref(p), ctypes.sizeof(ConvGemmParams))
+    return q
+
+
+def time_launch(lib, p, reps=10):
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        s = torch.cuda.current_stream().cuda_stream
+        rc = lib.aptp_conv_gemm(ctypes.byref(p), s)
+        if rc != 0:
+            return None
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for _ in range(reps):
+                lib.aptp_conv_gemm(ctypes.byref(p), torch.cuda.current_stream().cuda_stream)
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        g.replay(); g.replay(); g.replay()
+        e1.record(stream)
+        stream.synchronize()
+        return e0.elapsed_time(e1) / (3 * reps) * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    lib = ops._lib.load()
+    model = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
+    st = model.get_structure()
+    model.set_structure(ones_mask(st, dev) if args.dense else fixed_half_mask(st, dev))
+    B = args.batch
+    sample = torch.randn(B, 4, 64, 64, device=dev)
+    ehs = torch.randn(B, 77, 1024, device=dev)
+    t = torch.full((B,), 500, dtype=torch.int64, device=dev)
+    ops.TUNING = {}      # record with heuristics only
+    with torch.no_grad():
+        model(sample, t, ehs)
+        ops.LAUNCH_LOG = []
+        model(sample, t, ehs)
+        torch.cuda.synchronize()
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    uniq = {}
+    for rec in log:
+        p = rec["params"]
+        key = ops.tuning_key(p.B * p.Hout * p.Wout, p.N, p.Cin, p.KH * p.KW, p.stride, p.ups, p.act == ACT_GEGLU)
+        u = uniq.setdefault(key, {"rec": rec, "count": 0})
+        u["count"] += 1
+    print(f"{len(log)} launches, {len(uniq)} distinct", flush=True)
+    table, rows = {}, []
+    for key, u in uniq.items():
+        p0 = u["rec"]["params"]
+        M, nK = p0.B * p0.Hout * p0.Wout, p0.KH * p0.KW * (p0.cin_pad // 64)
+        base = clone_params(p0)
+        t_base = time_launch(lib, base)
+        tiles = [1, 3, 5, 6] if p0.act == ACT_GEGLU else [1, 2, 3, 4, 5, 6]
+        splits = [1, 2, 3, 4, 6, 8, 12, 16, 24]
+        if args.quick:
+            splits = [1, 2, 4, 8]
+        best = (t_base, base.tile, base.split_k)
+        for tl in tiles:
+            for sk in splits:
+                if sk > 1 and (nK // sk < 3 or M * p0.N * sk * 4 > ws.numel() or M >= 8192 and sk > 2):
+                    continue
+                q = clone_params(p0)
+                q.tile, q.split_k = tl, sk
+                q.workspace = ws.data_ptr() if sk > 1 else None
+                us = time_launch(lib, q)
+                if us is not None and us < best[0]:
+                    best = (us, tl, sk)
+        table[key] = {"tile": best[1], "split_k": best[2], "us": round(best[0], 2)}
+        fl = u["rec"]["flops"]
+        rows.append((best[0] * u["count"], key, u["count"], t_base, best, fl))
+        print(f"{key:36s} x{u['count']:2d} heur {t_base:7.1f} us (t{base.tile} s{base.split_k}) -> best {best[0]:7.1f} us "
+              f"(t{best[1]} s{best[2]})  {fl / best[0] / 1e6:6.1f} TF", flush=True)
+    rows.sort(reverse=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "tune_convs" + ("_dense" if args.dense else "") + ".txt"), "w") as f:
+        tot_h = sum(r[3] * r[2] for r in rows)
+        tot_b = sum(r[0] for r in rows)
+        f.write(f"# total conv_gemm time per forward: heuristic {tot_h / 1e3:.3f} ms -> tuned {tot_b / 1e3:.3f} ms\n")
+        for tot, key, cnt, tb, best, fl in rows:
+            f.write(f"{tot:8.1f} us  {key:36s} x{cnt:2d}  heur {tb:7.1f}  best {best[0]:7.1f} (t{best[1]} s{best[2]})  {fl / best[0] / 1e6:6.1f} TF\n")
+    path = os.path.join(ROOT, "gpurun_out", "tuning_gfx950.json")
+    old = {}
+    src = os.path.join(ROOT, "diffusion_pruning_amd", "tuning_gfx950.json")
+    if os.path.exists(src):
+        old = json.load(open(src))
+    old.update(table)
+    json.dump(old, open(path, "w"), indent=0, sort_keys=True)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""HyperStructure — the architecture predictor (pdm/models/hypernet/hypernet.py:27-153).
+
+70 Linear(768 -> w_i) width heads + one Linear(768 -> 14) depth head (1.25 M parameters).  The math is negligible next
+to the U-Net, so it stays PyTorch on the device; what matters is the call signature, the parameter
+names (``mh_fc.{i}.weight|bias``) and the arch-vector layout that the gated U-Net's ``set_structure`` consumes.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+import torch.nn as nn
+from torch.nn.utils.parametrizations import weight_norm
+
+from .estimation_utils import hard_concrete
+
+
+def _flat(list_of_lists):
+    return [v for sub in list_of_lists for v in sub]
+
+
+class HyperStructure(nn.Module):
+    def __init__(self, structure, input_dim: int = 768, wn_flag: bool = True, linear_bias: bool = False,
+                 single_arch_param: bool = False):
+        super().__init__()
+        self.config = dict(structure=structure, input_dim=input_dim, wn_flag=wn_flag, linear_bias=linear_bias,
+                           single_arch_param=single_arch_param)
+        self.structure = structure
+        self.input_dim, self.linear_bias, self.wn_flag = input_dim, linear_bias, wn_flag
+        self.width_list = _flat(structure["width"])
+        self.depth_list = _flat(structure["depth"])
+        self.single_arch_param = single_arch_param
+        total = sum(self.width_list) + sum(self.depth_list)
+        if single_arch_param:
+            self.arch = nn.Parameter(torch.randn(1, total))
+            self.arch_gs = torch.zeros(1, total)
+        else:
+            heads = [nn.Linear(input_dim, w, bias=linear_bias) for w in self.width_list]
+            heads.append(nn.Linear(input_dim, sum(self.depth_list), bias=linear_bias))
+            if wn_flag:
+                heads = [weight_norm(h) for h in heads]
+            self.mh_fc = nn.ModuleList(heads)
+            self.initialize_weights()
+
+    def initialize_weights(self):
+        for name, param in self.named_parameters():
+            if "weight" in name:
+                nn.init.orthogonal_(param)
+            elif "bias" in name:
+                nn.init.zeros_(param)
+
+    def forward(self, x):
+        if self.single_arch_param:
+            return self.arch          # one shared architecture for the whole batch (hypernet.py:66-68)
+        x = x.to(self.mh_fc[0].weight.device)
+        return torch.cat([head(x) for head in self.mh_fc], dim=1)
+
+    def print_param_stats(self):
+        for name, param in self.named_parameters():
+            if "weight" in name:
+                print(f"{name}: {param.mean()}, {param.std()}")
+
+    @staticmethod
+    def _split(inputs, width_list, n_depth, force_width_non_zero=False):
+        nw = sum(width_list)
+        assert inputs.shape[1] == nw + n_depth
+        widths, start = [], 0
+        for w in width_list:
+            seg = inputs[:, start:start + w]
+            if force_width_non_zero:
+                alive = hard_concrete(seg).sum(dim=1)
+                if not bool(alive.all()):
+                    seg = seg.clone()
+                    seg[alive == 0, 0] = seg[alive == 0, 0] + 0.5
+            widths.append(seg)
+            start += w
+        depths = [inputs[:, nw + i] for i in range(n_depth)]
+        return {"width": widths, "depth": depths}
+
+    def transform_structure_vector(self, inputs):
+        """[B, 1620] -> {"width": 70 x [B, w], "depth": 14 x [B]} (hypernet.py:86-101)"""
+        return self._split(inputs, self.width_list, sum(self.depth_list))
+
+    @classmethod
+    def transform_arch_vector(cls, inputs, structure, force_width_non_zero: bool = False):
+        """hypernet.py:103-129"""
+        return cls._split(inputs, _flat(structure["width"]), sum(_flat(structure["depth"])), force_width_non_zero)
+
+    @classmethod
+    def get_random_arch_vector(cls, target_ratio, structure):
+        """hypernet.py:131-153: per width segment int(ratio*w) random entries = 0.9, every depth entry = 0.9"""
+        parts = []
+        for w in _flat(structure["width"]):
+            seg = torch.zeros(1, w)
+            seg[0, torch.randperm(w)[:int(target_ratio * w)]] = 0.9
+            parts.append(seg)
+        for _ in range(sum(_flat(structure["depth"]))):
+            parts.append(torch.tensor([[0.9]]))
+        return torch.cat(parts, dim=1)
+
+    # ---- checkpoint helpers in the layout trainer.py:253-313 writes (config.json + weights) ------------------------
+    def save_pretrained(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.config, f)
+        torch.save(self.state_dict(), os.path.join(path, "diffusion_pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs):
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        cfg.update(kwargs)
+        m = cls(**cfg)
+        m.load_state_dict(torch.load(os.path.join(path, "diffusion_pytorch_model.bin"), map_location="cpu"))
+        return m

@@ -1,0 +1,216 @@
+"""StructureVectorQuantizer — the prompt router / architecture codebook (pdm/models/vq/quantizer.py:12-340).
+
+Routes each prompt's architecture vector to one of ``n_e`` codes (cosine assignment in eval, Sinkhorn optimal
+transport in training) and returns the code's gumbel-sigmoid relaxation (soft in training, hard_concrete in eval).
+Stays PyTorch on the device.  The two ``dist.all_reduce`` call sites of the distributed Sinkhorn
+(quantizer.py:284-285, 290-291) run over RCCL when ``torch.distributed`` is initialised with backend "nccl" on ROCm
+(gloo in the CPU tests); ``fused_sinkhorn_allreduce=True`` is the MI355X-first variant: the [K, B_loc] score matrix
+is all-gathered ONCE (a single small collective instead of 1 + sinkhorn_iterations latency-bound all-reduces) and
+the Sinkhorn iterations run redundantly on every rank — same result up to fp32 summation order.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .estimation_utils import gumbel_softmax_sample, hard_concrete, importance_gumbel_softmax_sample
+
+
+class StructureVectorQuantizer(nn.Module):
+    def __init__(self, n_e: int, structure: dict, beta: float = 0.25, remap=None, unknown_index: str = "random",
+                 sane_index_shape: bool = True, temperature: float = 0.4, base: int = 2, depth_order: list = None,
+                 non_zero_width: bool = True, sinkhorn_epsilon: float = 0.05, sinkhorn_iterations: int = 3,
+                 resource_aware_normalization: bool = True, optimal_transport: bool = True,
+                 fused_sinkhorn_allreduce: bool = False):
+        super().__init__()
+        self.config = dict(n_e=n_e, structure=structure, beta=beta, remap=remap, unknown_index=unknown_index,
+                           sane_index_shape=sane_index_shape, temperature=temperature, base=base,
+                           depth_order=depth_order, non_zero_width=non_zero_width, sinkhorn_epsilon=sinkhorn_epsilon,
+                           sinkhorn_iterations=sinkhorn_iterations,
+                           resource_aware_normalization=resource_aware_normalization,
+                           optimal_transport=optimal_transport)
+        if remap is not None:
+            raise NotImplementedError("index remapping (taming-transformers legacy) is unused by APTP's configs")
+        self.structure = structure
+        self.n_e, self.beta = n_e, beta
+        self.width_list = [w for sub in structure["width"] for w in sub]
+        self.width_list_sum = [sum(sub) for sub in structure["width"]]
+        self.depth_list = [d for sub in structure["depth"] for d in sub]
+        # one embedding dim per width entry plus one per depth-gated sub-block (quantizer.py:43-48)
+        self.vq_embed_dim = sum(self.width_list) + sum(1 for d in structure["depth"] if d == [1])
+        edges = [0] + np.cumsum(self.width_list_sum).tolist()
+        self.width_intervals = [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+        self.depth_indices = (sum(self.width_list) - 1 + np.cumsum(self.depth_list)).tolist()
+        n_depth = sum(self.depth_list)
+        self.input_depth_order = list(range(n_depth)) if depth_order is None else depth_order
+        self.depth_order = [i % n_depth for i in self.input_depth_order]
+        seg = torch.tensor(self.width_list + [d for d in self.depth_list if d != 0])
+        self.template = (1.0 / torch.repeat_interleave(seg, seg).float()).requires_grad_(False)
+        self.prunable_macs_template = None
+        self.resource_effect_normalization = True if resource_aware_normalization is None else resource_aware_normalization
+        self.embedding = nn.Embedding(n_e, self.vq_embed_dim)
+        nn.init.orthogonal_(self.embedding.weight)
+        self.embedding_gs = nn.Parameter(self.embedding.weight.detach().clone(), requires_grad=False)
+        self.remap = None
+        self.re_embed = n_e
+        self.sane_index_shape = sane_index_shape
+        self.temperature, self.base = temperature, base
+        self.non_zero_width = non_zero_width
+        self.optimal_transport = optimal_transport
+        self.sinkhorn_epsilon, self.sinkhorn_iterations = sinkhorn_epsilon, sinkhorn_iterations
+        self.fused_sinkhorn_allreduce = fused_sinkhorn_allreduce
+
+    # ---- forward (quantizer.py:136-169) ---------------------------------------------------------------------------
+    def forward(self, z: torch.Tensor) -> Tuple[torch.Tensor, Tuple]:
+        z = z.contiguous()
+        z_flat = z.view(-1, self.vq_embed_dim)
+        if self.training:
+            codes = self.gumbel_sigmoid_trick(self.embedding.weight)      # gradient reaches the codebook
+            self.embedding_gs.data = codes.detach()
+            if self.optimal_transport:
+                idx = self.get_optimal_transport_min_encoding_indices(z_flat)
+            else:
+                idx = self.get_cosine_sim_min_encoding_indices(z_flat)
+        else:
+            codes = self.embedding_gs.detach()
+            idx = self.get_cosine_sim_min_encoding_indices(z_flat)
+        z_q = codes[idx].view(z.shape).contiguous()
+        if self.sane_index_shape:
+            idx = idx.reshape(z_q.shape[0])
+        if not self.training:
+            z_q = hard_concrete(z_q)
+        return z_q, (None, None, idx)
+
+    def get_codebook_entry(self, indices: torch.LongTensor, shape=None) -> torch.Tensor:
+        z_q = self.embedding(indices)
+        if shape is not None:
+            z_q = z_q.view(shape).contiguous()
+        return z_q
+
+    def get_codebook_entry_gumbel_sigmoid(self, indices: torch.LongTensor, shape=None, hard: bool = False):
+        z_q = self.gumbel_sigmoid_trick(self.get_codebook_entry(indices, shape).contiguous())
+        return hard_concrete(z_q) if hard else z_q
+
+    # ---- relaxation (quantizer.py:196-231) ---------------------------------------------------------------------------
+    def _transform_width_vector(self, inputs):
+        assert inputs.shape[1] == sum(self.width_list)
+        out, s = [], 0
+        for w in self.width_list:
+            out.append(inputs[:, s:s + w])
+            s += w
+        return out
+
+    def gumbel_sigmoid_trick(self, z_q: torch.Tensor):
+        nw = sum(self.width_list)
+        zw, zd = z_q[:, :nw], z_q[:, nw:]
+        fixed = not self.training
+        # depth first, then the width segments: the order fixes the host-RNG stream in training mode
+        d_sorted = importance_gumbel_softmax_sample(zd, temperature=self.temperature, offset=self.base, fixed_seed=fixed)
+        d = torch.zeros_like(d_sorted)
+        d[:, self.depth_order] = d_sorted
+        w = [gumbel_softmax_sample(seg, temperature=self.temperature, offset=self.base,
+                                   force_width_non_zero=self.non_zero_width, fixed_seed=fixed)
+             for seg in self._transform_width_vector(zw)]
+        return torch.cat([torch.cat(w, dim=1), d], dim=1)
+
+    def print_param_stats(self):
+        for name, param in self.named_parameters():
+            if "weight" in name:
+                print(f"{name}: {param.mean()}, {param.std()}")
+
+    # ---- normalisation (quantizer.py:233-261) --------------------------------------------------------------------------
+    def width_depth_normalize(self, inputs):
+        self.template = self.template.to(inputs.device)
+        if self.resource_effect_normalization:
+            self.prunable_macs_template = self.prunable_macs_template.to(inputs.device)
+        out = hard_concrete(inputs.clone())
+        for i, has_depth in enumerate(self.depth_list):
+            if has_depth != 0:
+                lo, hi = self.width_intervals[i]
+                di = self.depth_indices[i]
+                out[:, lo:hi] = inputs[:, lo:hi] * inputs[:, di:di + 1]
+        out = out * torch.sqrt(self.template).detach()
+        if self.resource_effect_normalization:
+            out = out * self.prunable_macs_template.detach()
+        return out
+
+    def set_prunable_macs_template(self, prunable_macs_list):
+        depth_template = [[sum(prunable_macs_list[i])] for i, d in enumerate(self.depth_list) if d == 1]
+        prunable_macs_list += depth_template      # (the reference extends the caller's list in place)
+        flat = [v for sub in prunable_macs_list for v in sub]
+        self.prunable_macs_template = torch.repeat_interleave(
+            torch.tensor(flat), torch.tensor(self.width_list + [1] * len(depth_template)))
+
+    # ---- assignment (quantizer.py:263-340) ----------------------------------------------------------------------------
+    def _unit(self, x):
+        x = self.width_depth_normalize(x)
+        return x / x.norm(dim=-1, keepdim=True)
+
+    @torch.no_grad()
+    def get_cosine_sim_min_encoding_indices(self, z: torch.Tensor) -> torch.Tensor:
+        u = self._unit(self.gumbel_sigmoid_trick(z))
+        v = self._unit(self.embedding_gs)
+        return torch.argmax(u @ v.t(), dim=-1)
+
+    @torch.no_grad()
+    def _sinkhorn(self, out: torch.Tensor, distributed: bool) -> torch.Tensor:
+        Q = torch.exp(out / self.sinkhorn_epsilon).t()        # K x B_local
+        world = dist.get_world_size() if distributed else 1
+        B, K = Q.shape[1] * world, Q.shape[0]
+        total = torch.sum(Q)
+        if distributed:
+            dist.all_reduce(total)
+        Q /= total
+        for _ in range(self.sinkhorn_iterations):
+            rows = torch.sum(Q, dim=1, keepdim=True)
+            if distributed:
+                dist.all_reduce(rows)
+            Q /= rows
+            Q /= K
+            Q /= torch.sum(Q, dim=0, keepdim=True)
+            Q /= B
+        Q *= B
+        return Q.t()
+
+    @torch.no_grad()
+    def _sinkhorn_fused(self, out: torch.Tensor) -> torch.Tensor:
+        """One all-gather of the local score block, then the global Sinkhorn computed redundantly on every rank."""
+        world, rank = dist.get_world_size(), dist.get_rank()
+        blocks = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(blocks, out.contiguous())
+        full = self._sinkhorn(torch.cat(blocks, dim=0), distributed=False)
+        n = out.shape[0]
+        return full[rank * n:(rank + 1) * n]
+
+    @torch.no_grad()
+    def get_optimal_transport_min_encoding_indices(self, a: torch.Tensor) -> torch.Tensor:
+        a = self._unit(self.gumbel_sigmoid_trick(a))
+        codes = self._unit(self.embedding_gs)
+        out = a @ codes.t()
+        if dist.is_available() and dist.is_initialized():
+            Q = self._sinkhorn_fused(out) if self.fused_sinkhorn_allreduce else self._sinkhorn(out, True)
+        else:
+            Q = self._sinkhorn(out, False)
+        return torch.argmax(Q, dim=-1)
+
+    # ---- checkpoint helpers ----------------------------------------------------------------------------------------------
+    def save_pretrained(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.config, f)
+        torch.save(self.state_dict(), os.path.join(path, "diffusion_pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs):
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        cfg.update(kwargs)
+        m = cls(**cfg)
+        m.load_state_dict(torch.load(os.path.join(path, "diffusion_pytorch_model.bin"), map_location="cpu"))
+        return m

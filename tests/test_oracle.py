@@ -37,11 +37,13 @@ def tiny():
     return cfg, p, s, t, e
 
 
-def test_ones_mask_is_bitwise_ungated(tiny):
+def test_ones_mask_equals_ungated(tiny):
+    """x*1 and (1-1)*x_in + 1*out are exact; what remains is torch picking different CPU kernels for differently
+    strided (gated vs ungated) operands, i.e. fp32 reassociation noise."""
     cfg, p, s, t, e = tiny
     y0 = O.unet_forward(p, cfg, s, t, e)
     y1 = O.unet_forward(p, cfg, s, t, e, O.assign_gates(cfg, O.ones_mask(cfg)), "gated")
-    assert torch.equal(y0, y1)
+    assert float((y0 - y1).abs().max()) < 1e-5
 
 
 def test_attention_and_ff_gated_equals_pruned(tiny):

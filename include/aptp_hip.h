@@ -67,7 +67,7 @@ typedef struct {
   const float* colgate; /* [gate_B, Nlogical/gate_group] or NULL */
   int32_t gate_group, gate_B;
   int32_t act;          /* APTP_ACT_* */
-  const float* corr;    /* [corr_B, 9, N] or NULL; class = 3*rowclass + colclass, class 1 = interior */
+  const float* corr;    /* [corr_B, 9, N] or NULL; class = 3*rowclass + colclass (0 first / 1 interior / 2 last row or column), class 4 = interior */
   int32_t corr_B;
   const void* residual; /* bf16 [M, ldres] or NULL */
   int64_t ldres;

@@ -93,6 +93,7 @@ class CtxBundle:
     """Text states plus the batched cross-attention K/V projections of every attn2 (one GEMM per forward)."""
     ehs: torch.Tensor                        # bf16 [B, 77, X]
     kv: Dict[int, torch.Tensor] = field(default_factory=dict)     # id(attn2) -> bf16 [B, 77, 2*hl*64] view
+    key: Any = None                          # identity of the packed-weight plans the projections were made with
 
 
 def _live_index(mask: torch.Tensor, group: int) -> torch.Tensor:
@@ -947,6 +948,30 @@ class UNet2DConditionModelGated(nn.Module):
                     m.set_host_value(h)
         self._host_map = {}
 
+    # ---- MAC accounting (unet_2d_conditional.py:2124-2181; trainer.py:1256-1306) ----------------------------------------
+    def count_macs(self, latent_h: int, latent_w: Optional[int] = None, text_len: int = 77):
+        """Analytic stand-in for the reference's hook-based count_ops_and_params on a batch-1 forward: assigns every
+        module's MAC constant, then fills prunable_macs_list / resource_info_dict the way Pruner.count_macs does
+        (with the all-ones structure installed by the caller, trainer.py:1262-1266)."""
+        from . import macs
+        macs.assign_module_macs(self, latent_h, latent_w, text_len)
+        sanity = self.calc_macs()
+        self.prunable_macs_list = [[e / sanity["prunable_macs"] for e in elem] for elem in self.get_prunable_macs()]
+        self.resource_info_dict = sanity
+        return sanity
+
+    def calc_macs(self):
+        from . import macs
+        return macs.unet_calc_macs(self)
+
+    def get_prunable_macs(self):
+        from . import macs
+        return macs.unet_get_prunable_macs(self)
+
+    def get_block_utilization(self):
+        from . import macs
+        return macs.unet_get_block_utilization(self)
+
     # ---- model-level packed weights ---------------------------------------------------------------------------------
     def _resnets(self):
         return [m for m in self.modules() if isinstance(m, ResnetBlock2DWidthGated)]
@@ -1011,6 +1036,36 @@ class UNet2DConditionModelGated(nn.Module):
         self._batched[key] = bp
         return bp
 
+    def _project_context(self, encoder_hidden_states, bp, dev) -> CtxBundle:
+        ehs = encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous()
+        # projections made with value-dependent (soft / per-sample) gates in the epilogue must not be reused
+        reusable = not any(dense for (_, dense, _) in bp["kv_gates"])
+        ctx = CtxBundle(ehs=ehs, key=bp["key"] if reusable else None)
+        if bp["kv_slots"]:
+            gkw = {}
+            if any(dense for (_, dense, _) in bp["kv_gates"]):
+                cols = []
+                for gate, dense, hl in bp["kv_gates"]:
+                    g = gate.gate_f.detach().to(device=dev, dtype=torch.float32) if dense else None
+                    bg = max(gt.gate_f.shape[0] for gt, d_, _ in bp["kv_gates"] if d_)
+                    if g is None:
+                        g = torch.ones(bg, hl, device=dev)
+                    elif g.shape[0] != bg:
+                        g = g.repeat(bg // g.shape[0], 1)
+                    cols.append(g.repeat(1, 2))
+                gkw = dict(colgate=torch.cat(cols, 1).contiguous(), gate_group=64)
+            kv_all = ops.linear(ehs, bp["kv_pw"], **gkw)
+            for aid, off, n in bp["kv_slots"]:
+                ctx.kv[aid] = kv_all[..., off:off + n]
+        return ctx
+
+    @torch.no_grad()
+    def precompute_context(self, encoder_hidden_states: torch.Tensor) -> CtxBundle:
+        """Project the text states through every live cross-attention K/V weight once (valid until the next
+        set_structure / weight change); pass the result as ``encoder_hidden_states`` to forward()."""
+        dev = encoder_hidden_states.device
+        return self._project_context(encoder_hidden_states, self._batched_packs(dev), dev)
+
     # ---- forward (unet_2d_conditional.py:1415-1726) -------------------------------------------------------------------
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
                 timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
@@ -1043,25 +1098,14 @@ class UNet2DConditionModelGated(nn.Module):
         for rid, off, npad in bp["temb_slots"]:
             temb.proj[rid] = tproj[:, off:off + npad]
 
-        # text states: one batched K/V projection for all cross-attention layers
-        ehs = encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous()
-        ctx = CtxBundle(ehs=ehs)
-        if bp["kv_slots"]:
-            gkw = {}
-            if any(dense for (_, dense, _) in bp["kv_gates"]):
-                cols = []
-                for gate, dense, hl in bp["kv_gates"]:
-                    g = gate.gate_f.detach().to(device=dev, dtype=torch.float32) if dense else None
-                    bg = max(gt.gate_f.shape[0] for gt, d_, _ in bp["kv_gates"] if d_)
-                    if g is None:
-                        g = torch.ones(bg, hl, device=dev)
-                    elif g.shape[0] != bg:
-                        g = g.repeat(bg // g.shape[0], 1)
-                    cols.append(g.repeat(1, 2))
-                gkw = dict(colgate=torch.cat(cols, 1).contiguous(), gate_group=64)
-            kv_all = ops.linear(ehs, bp["kv_pw"], **gkw)
-            for aid, off, n in bp["kv_slots"]:
-                ctx.kv[aid] = kv_all[..., off:off + n]
+        # text states: one batched K/V projection for all cross-attention layers (reused as-is when the caller
+        # hands in the CtxBundle of precompute_context: K/V depend only on the prompt, not on the denoise step)
+        if isinstance(encoder_hidden_states, CtxBundle) and encoder_hidden_states.key is not None \
+                and encoder_hidden_states.key == bp["key"]:
+            ctx = encoder_hidden_states
+        else:
+            ehs_in = encoder_hidden_states.ehs if isinstance(encoder_hidden_states, CtxBundle) else encoder_hidden_states
+            ctx = self._project_context(ehs_in, bp, dev)
 
         # 2. pre-process: conv_in on the channel-padded NHWC input
         x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libaptp_hip.so")
 
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x160, TILE_64x128, TILE_64x160, TILE_128x64, TILE_64x64 = range(7)
+(TILE_DMA_128x128, TILE_DMA_128x160, TILE_DMA_64x128, TILE_DMA_64x160, TILE_DMA_128x64, TILE_DMA_64x64) = range(7, 13)
 
 
 class ConvGemmParams(Structure):

@@ -10,6 +10,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // (HIP's uint4 struct makes value selects go through scratch)
+
 struct AttnK {
   const __bf16* q; int64_t qsb, qsl;
   const __bf16* k; int64_t ksb, ksl;
@@ -25,11 +27,23 @@ __device__ __forceinline__ int vt_pos(int key) {
   return (key & ~15) | ((o & 4) << 1) | ((o & 8) >> 1) | (o & 3);
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
-  __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * 64];   // [key][d], 16B chunks XOR-swizzled by (key>>1)&7
-  __shared__ __attribute__((aligned(16))) __bf16 Vt[64 * 64];   // [d][vt_pos(key)], chunks XOR-swizzled by (d>>1)&7
+// NG = number of key-range groups per workgroup (1 or 2).  With NG = 2 the workgroup has 8 waves: waves 0-3 sweep the
+// first half of the key tiles, waves 4-7 the second half, for the SAME 128 queries, and the two partial softmax states
+// are merged through LDS at the end.  This doubles the waves per SIMD when B*heads*Lq/32 alone cannot fill the chip
+// (SD-2.1 level 0: 1024 waves for 1024 SIMDs), so one wave's softmax VALU work overlaps the other's MFMAs.
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
+  // one LDS array: per group a [key][d] K image (chunks XOR-swizzled by (key>>1)&7) and a [d][vt_pos(key)] V^T image
+  // (chunks XOR-swizzled by (d>>1)&7); reused at the end for the group merge (NG == 2)
+  constexpr int KV_ELEMS = 2 * 64 * 64;
+  constexpr int MERGE_FLOATS = (NG == 2) ? 256 * 34 : 0;
+  constexpr int LDS_BYTES = (NG * KV_ELEMS * 2 > MERGE_FLOATS * 4) ? NG * KV_ELEMS * 2 : MERGE_FLOATS * 4;
+  __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+  const int grp = (NG == 2) ? (int)(threadIdx.x >> 8) : 0;
+  __bf16* Ks = reinterpret_cast<__bf16*>(lds_raw) + grp * KV_ELEMS;
+  __bf16* Vt = Ks + 64 * 64;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -45,10 +59,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
     const bool ok = qrow < p.Lq;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      uint4 t = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) t = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow * p.qsl + 16 * s + 8 * hh);
-      union { uint4 u; bf16x8 v; } cv; cv.u = t;
-      qf[s] = cv.v;
+      const int qc = ok ? qrow : p.Lq - 1;
+      u32x4 t = *reinterpret_cast<const u32x4*>(qp + (int64_t)qc * p.qsl + 16 * s + 8 * hh);
+      t = ok ? t : (u32x4){0u, 0u, 0u, 0u};
+      qf[s] = __builtin_bit_cast(bf16x8, t);
     }
   }
 
@@ -56,17 +70,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
   const int chunk = tid & 7;
   const int krow = tid >> 3;        // K: rows krow, krow+32
   const int kpair = tid >> 3;       // V: keys 2*kpair, 2*kpair+1
-  uint4 kreg[2], vreg[2];
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  u32x4 kreg[2], vreg[2];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   auto load_kv = [&](int tile) {
     const int key0 = tile * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      // rows past Lk: load a clamped (valid) row unconditionally, then zero the VALUE (a pointer select against a
+      // local zero would put the staging registers in scratch)
       const int key = key0 + krow + 32 * i;
-      kreg[i] = key < p.Lk ? *reinterpret_cast<const uint4*>(kp + (int64_t)key * p.ksl + chunk * 8) : zero4;
+      const int keyc = key < p.Lk ? key : p.Lk - 1;
+      const u32x4 kq = *reinterpret_cast<const u32x4*>(kp + (int64_t)keyc * p.ksl + chunk * 8);
+      kreg[i] = key < p.Lk ? kq : zero4;
       const int vkey = key0 + 2 * kpair + i;
-      vreg[i] = vkey < p.Lk ? *reinterpret_cast<const uint4*>(vp + (int64_t)vkey * p.vsl + chunk * 8) : zero4;
+      const int vkeyc = vkey < p.Lk ? vkey : p.Lk - 1;
+      const u32x4 vq = *reinterpret_cast<const u32x4*>(vp + (int64_t)vkeyc * p.vsl + chunk * 8);
+      vreg[i] = vkey < p.Lk ? vq : zero4;
     }
   };
   auto store_kv = [&]() {
@@ -74,17 +94,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
     for (int i = 0; i < 2; ++i) {
       const int r = krow + 32 * i;
       const int sw = chunk ^ ((r >> 1) & 7);
-      *reinterpret_cast<uint4*>(Ks + r * 64 + sw * 8) = kreg[i];
+      *reinterpret_cast<u32x4*>(Ks + r * 64 + sw * 8) = kreg[i];
     }
     // transposed V: dword (V[2kp][d], V[2kp+1][d]) -> Vt[d][vt_pos(2kp) .. +1]
-    union { uint4 u; unsigned short e[8]; } v0, v1;
-    v0.u = vreg[0]; v1.u = vreg[1];
     const int pos = vt_pos(2 * kpair);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int d = chunk * 8 + e;
       const int sw = (pos >> 3) ^ ((d >> 1) & 7);
-      const uint32_t w = (uint32_t)v0.e[e] | ((uint32_t)v1.e[e] << 16);
+      const uint32_t a = vreg[0][e >> 1], b = vreg[1][e >> 1];
+      const uint32_t w = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
       *reinterpret_cast<uint32_t*>(Vt + d * 64 + sw * 8 + (pos & 7)) = w;
     }
   };
@@ -96,13 +115,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
     for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (p.Lk + 63) / 64;
-  load_kv(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  const int ntiles_all = (p.Lk + 63) / 64;
+  const int per_grp = (ntiles_all + NG - 1) / NG;
+  const int t_begin = grp * per_grp;
+  const int t_end = (t_begin + per_grp < ntiles_all) ? t_begin + per_grp : ntiles_all;   // may be empty for grp 1
+  if (t_begin < t_end) load_kv(t_begin);
+  for (int it = 0; it < per_grp; ++it) {       // uniform trip count: both groups meet at every barrier
+    const int tile = t_begin + it;
+    const bool active = tile < t_end;
     __syncthreads();   // everyone finished reading the previous tile
-    store_kv();
+    if (active) store_kv();
     __syncthreads();
-    if (tile + 1 < ntiles) load_kv(tile + 1);
+    if (!active) continue;
+    if (tile + 1 < t_end) load_kv(tile + 1);
 
     // ---- S^T = K . Q^T -------------------------------------------------------------------------------------------
     f32x16 sacc[2];
@@ -121,15 +146,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
     // sacc[t][r] = score(key = tile*64 + 32t + (r&3) + 8(r>>2) + 4hh, query = q0 + lq)
     const int key_base = tile * 64 + 4 * hh;
     float mx = -INFINITY;
+    if (tile * 64 + 64 <= p.Lk) {              // full tile (wave-uniform): no key masking
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key_base + 32 * t + (r & 3) + 8 * (r >> 2);
-        const float sv = key < p.Lk ? sacc[t][r] * p.c : -INFINITY;
-        sacc[t][r] = sv;
-        mx = fmaxf(mx, sv);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float sv = sacc[t][r] * p.c;
+          sacc[t][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + 32 * t + (r & 3) + 8 * (r >> 2);
+          const float sv = key < p.Lk ? sacc[t][r] * p.c : -INFINITY;
+          sacc[t][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);       // finite: every tile holds >= 1 valid key
     const float alpha = exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
@@ -169,6 +205,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnK p) {
     }
   }
 
+  if (NG == 2) {
+    // merge the two key-range groups: group 1 publishes (m, l, O) per lane, group 0 combines
+    float* mg = reinterpret_cast<float*>(lds_raw);
+    __syncthreads();                            // all K/V tile reads are done; the LDS array is free
+    if (grp == 1) {
+      float* dst = mg + tid * 34;
+      dst[0] = m_run; dst[1] = l_run;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[2 + u * 16 + r] = oacc[u][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float* src = mg + tid * 34;
+    const float m1 = src[0], l1 = src[1];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);      // m_run is finite (group 0 always owns >= 1 tile)
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[u][r] = oacc[u][r] * a0 + src[2 + u * 16 + r] * a1;
+  }
+
   // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------------
   const int qrow = q0 + lq;
   if (qrow < p.Lq) {
@@ -205,7 +266,11 @@ extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream
   k.B = p->B; k.H = p->heads; k.Lq = p->Lq; k.Lk = p->Lk;
   k.c = p->scale * 1.44269504088896340736f;
   dim3 grid((p->Lq + 127) / 128, p->heads, p->B);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+  // split the key range over two wave groups when the query-parallel grid alone gives < 2 waves per SIMD
+  const int64_t waves = (int64_t)grid.x * grid.y * grid.z * 4;
+  const int ntiles = (p->Lk + 63) / 64;
+  if (ntiles >= 2 && waves < 2 * 1024) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
   APTP_LAUNCH_CHECK();
   return APTP_OK;
 }

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
       int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
       const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE;
       iy >>= p.ups; ix >>= p.ups;
-      const unsigned off = (unsigned)(((int64_t)(a_pix0[i] + iy * p.Win + ix) * p.ldx + c) * 2);
+      const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31 (checked on the host)
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ok ? off : OOB, 0, 0);
     }
     const unsigned koff = (unsigned)l_kt * (BK * 2);
@@ -308,6 +308,184 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: same tiling / LDS image / MFMA schedule / epilogue, but the operand tiles are copied global -> LDS
+// directly (global_load_lds_dwordx4, 16 B per lane, destination = wave-uniform base + lane*16) instead of being staged
+// through VGPRs and ds_write_b128.  The LDS image stays lane-linear per wave-instruction (8 rows x 128 B), so the XOR
+// swizzle is applied to the per-lane SOURCE chunk (slot s of row r receives chunk s ^ ((r>>1)&7)) and the same XOR is
+// used by the fragment reads.  Zero padding / ragged tails: an invalid lane reads 16 zero bytes from g_zero16.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ uint4 g_zero16[2];
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MF = WTM / 16, NF = WTN / 16;
+  constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * (BM + BN) * BK];
+  __bf16* As = smem;
+  __bf16* Bs = smem + 2 * BM * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kz = blockIdx.y;
+  const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
+  const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+
+  const int rowbase = tid >> 3;
+  const int schunk = (tid & 7) ^ ((rowbase >> 1) & 7);      // source chunk that lands in this lane's LDS slot
+  const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+  int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS];
+#pragma unroll
+  for (int i = 0; i < A_PASS; ++i) {
+    const int m = m0 + rowbase + 32 * i;
+    if (m < p.M) {
+      const int b = m / p.HW, rem = m - b * p.HW;
+      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      a_pix0[i] = b * p.Hin * p.Win;
+    } else {
+      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0;
+    }
+  }
+  const char* b_src[B_PASS];
+#pragma unroll
+  for (int i = 0; i < B_PASS; ++i) {
+    const int n = n0 + rowbase + 32 * i;
+    b_src[i] = n < p.N ? reinterpret_cast<const char*>(p.w) + ((int64_t)n * p.Ktot + schunk * 8) * 2 : nullptr;
+  }
+
+  int l_kt = kt_begin;
+  int l_tap = kt_begin / p.ncc;
+  int l_cc = kt_begin - l_tap * p.ncc;
+  int l_ky = l_tap / p.KW;
+  int l_kx = l_tap - l_ky * p.KW;
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+
+  auto issue_tile = [&](int buf) {
+    const int c = l_cc * BK + schunk * 8;
+    const bool c_ok = c < p.Cin;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
+      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE;
+      iy >>= p.ups; ix >>= p.ups;
+      const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31
+      const uint64_t va = reinterpret_cast<uint64_t>(p.x) + off, vz = reinterpret_cast<uint64_t>(zsrc);
+      const char* src = reinterpret_cast<const char*>(ok ? va : vz);
+      __bf16* dst = As + (buf * BM + wave * 8 + 32 * i) * BK;      // wave-uniform; lane l lands at dst + l*16 B
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      const uint64_t vb = reinterpret_cast<uint64_t>(b_src[i]) + (unsigned)l_kt * (unsigned)(BK * 2);
+      const char* src = reinterpret_cast<const char*>(b_src[i] ? vb : reinterpret_cast<uint64_t>(zsrc));
+      __bf16* dst = Bs + (buf * BN + wave * 8 + 32 * i) * BK;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+    }
+    ++l_kt;
+    if (++l_cc == p.ncc) {
+      l_cc = 0;
+      if (++l_kx == p.KW) { l_kx = 0; ++l_ky; }
+    }
+  };
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[MF], wf[NF];
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int r = wm * WTM + i * 16 + frow;
+        const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+        af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * BM + r) * BK + sw * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int r = wn * WTN + j * 16 + frow;
+        const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+        wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * BN + r) * BK + sw * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    issue_tile(0);
+    __syncthreads();                       // (the compiler drains vmcnt(0) for the LDS-DMA before the barrier)
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) issue_tile(buf ^ 1);   // in flight during the MFMAs below
+      compute(buf);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  if (p.split_k > 1) {
+    float* ws = p.ws + (int64_t)kz * p.M * p.ws_ld;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        float4 o; o.x = acc[i][j][0]; o.y = acc[i][j][1]; o.z = acc[i][j][2]; o.w = acc[i][j][3];
+        *reinterpret_cast<float4*>(ws + (int64_t)m * p.ws_ld + n) = o;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    if (m >= p.M) continue;
+    int b, cls;
+    row_info(p, m, b, cls);
+    if (p.act == APTP_ACT_GEGLU) {
+      if constexpr (NF % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NF; j += 2) {
+          const int n = n0 + wn * WTN + j * 16 + fq * 4;
+          if (n >= p.N) continue;
+          float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+          epilogue_quad<true>(p, m, b, cls, n, h, g);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        epilogue_quad<false>(p, m, b, cls, n, h, h);
+      }
+    }
+  }
+}
+
 // split-K reducer + epilogue: one thread per (row, 4 packed columns)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
   const int quads = (p.act == APTP_ACT_GEGLU) ? p.N / 8 : p.N / 4;   // GEGLU: one thread per h-quad (+ its g-quad)
@@ -335,7 +513,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
 }
 
 struct TileCfg { int bm, bn; };
-const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64}};
+const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},
+                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64}};   // 7..12: LDS-DMA variants
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
   if (p->tile != APTP_TILE_AUTO) return p->tile;
@@ -407,6 +586,13 @@ void launch_tile(const KParams& k, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
 }
 
+template <int BM, int BN>
+void launch_tile_dma(const KParams& k, hipStream_t s) {
+  const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
+  dim3 grid(tiles, k.split_k, 1);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
+}
+
 }  // namespace
 
 extern "C" int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p) {
@@ -435,7 +621,8 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   if (k.split_k > 1) APTP_CHECK(k.ws != nullptr && ((uintptr_t)k.ws % 16) == 0, "conv_gemm: split_k > 1 needs a 16B-aligned workspace");
   hipStream_t s = (hipStream_t)stream;
   int t = pick_tile(p, k.M);
-  if (k.act == APTP_ACT_GEGLU && (t == APTP_TILE_128x160 || t == APTP_TILE_64x160)) {
+  if (t < 0 || t > 12) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
+  if (k.act == APTP_ACT_GEGLU && (kTiles[t < 13 ? t : 0].bn == 160)) {
     aptp_set_error("conv_gemm: GEGLU cannot use a 160-wide tile");
     return APTP_EINVAL;
   }
@@ -446,6 +633,12 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_64x160: launch_tile<64, 160>(k, s); break;
     case APTP_TILE_128x64: launch_tile<128, 64>(k, s); break;
     case APTP_TILE_64x64: launch_tile<64, 64>(k, s); break;
+    case APTP_TILE_DMA_128x128: launch_tile_dma<128, 128>(k, s); break;
+    case APTP_TILE_DMA_128x160: launch_tile_dma<128, 160>(k, s); break;
+    case APTP_TILE_DMA_64x128: launch_tile_dma<64, 128>(k, s); break;
+    case APTP_TILE_DMA_64x160: launch_tile_dma<64, 160>(k, s); break;
+    case APTP_TILE_DMA_128x64: launch_tile_dma<128, 64>(k, s); break;
+    case APTP_TILE_DMA_64x64: launch_tile_dma<64, 64>(k, s); break;
     default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
   }
   APTP_LAUNCH_CHECK();

@@ -4,6 +4,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
 // ------------------------------------------------------------------------------------------------------------
 // GroupNorm
 //   stage 1 (gn_stats): grid (nchunk, B); each workgroup reduces a slab of rows to per-group (sum, sumsq)
@@ -102,6 +104,41 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
   __shared__ float mean_s[32], rstd_s[32];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
+  const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
+  const bool active = rl < p.RPAR;
+  // Issue every independent global load up front (gamma/beta of this thread's channels, the first rows of x, the
+  // stage-1 partials) so the workgroup pays ONE memory latency before it starts streaming, not three in a row.
+  float ga[NP][8], be[NP][8];
+#pragma unroll
+  for (int pg = 0; pg < NP; ++pg) {
+    const int o = ot + pg * 256;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = o * 8 + e;
+      const bool ok = active && o < p.CO && c < p.C;
+      ga[pg][e] = ok ? p.gamma[c] : 0.f;
+      be[pg][e] = ok ? p.beta[c] : 0.f;
+    }
+  }
+  const int r0 = (int)(((int64_t)p.HW * chunk) / gridDim.x), r1 = (int)(((int64_t)p.HW * (chunk + 1)) / gridDim.x);
+  const __bf16* xb = p.x + ((int64_t)b * p.HW) * p.ldx;
+  __bf16* yb = p.y + ((int64_t)b * p.HW) * p.ldy;
+  constexpr int U = 2;
+  u32x4 q[U][NP];
+  auto load_rows = [&](int r) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = r + u * p.RPAR;
+#pragma unroll
+      for (int pg = 0; pg < NP; ++pg) {
+        const int o = ot + pg * 256;
+        const bool ok = active && rr < r1 && o < p.CO;
+        const int rc = ok ? rr : r0, oc = ok ? o : 0;          // clamped, always-valid address; value unused if !ok
+        q[u][pg] = *reinterpret_cast<const u32x4*>(xb + (int64_t)rc * p.ldx + oc * 8);
+      }
+    }
+  };
+  load_rows(r0 + rl);
   {
     // fold the stage-1 partials: 8 threads per group, fixed order => deterministic
     const int g = tid >> 3, sub = tid & 7;
@@ -125,8 +162,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
     }
   }
   __syncthreads();
-  const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
-  if (rl >= p.RPAR) return;
+  if (!active) return;
   float sc[NP][8], sh[NP][8];
   unsigned valid[NP];
 #pragma unroll
@@ -139,9 +175,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
     for (int e = 0; e < 8; ++e) {
       const int c = c0 + e;
       if (o < p.CO && c < p.C) {
-        const float k = rstd_s[g] * p.gamma[c];
+        const float k = rstd_s[g] * ga[pg][e];
         sc[pg][e] = k;
-        sh[pg][e] = p.beta[c] - mean_s[g] * k;
+        sh[pg][e] = be[pg][e] - mean_s[g] * k;
         valid[pg] |= 1u << e;
       } else {
         sc[pg][e] = 0.f; sh[pg][e] = 0.f;
@@ -149,22 +185,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
       if (++rem == p.cg) { rem = 0; ++g; }
     }
   }
-  const int r0 = (int)(((int64_t)p.HW * chunk) / gridDim.x), r1 = (int)(((int64_t)p.HW * (chunk + 1)) / gridDim.x);
-  const __bf16* xb = p.x + ((int64_t)b * p.HW) * p.ldx;
-  __bf16* yb = p.y + ((int64_t)b * p.HW) * p.ldy;
-  constexpr int U = 2;
   for (int r = r0 + rl; r < r1; r += p.RPAR * U) {
-    uint4 q[U][NP];
+    u32x4 cur[U][NP];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int rr = r + u * p.RPAR;
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int pg = 0; pg < NP; ++pg) {
-        const int o = ot + pg * 256;
-        q[u][pg] = make_uint4(0u, 0u, 0u, 0u);
-        if (rr < r1 && o < p.CO) q[u][pg] = *reinterpret_cast<const uint4*>(xb + (int64_t)rr * p.ldx + o * 8);
-      }
-    }
+      for (int pg = 0; pg < NP; ++pg) cur[u][pg] = q[u][pg];
+    if (r + p.RPAR * U < r1) load_rows(r + p.RPAR * U);      // next rows in flight while these are transformed
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rr = r + u * p.RPAR;
@@ -173,7 +200,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
         const int o = ot + pg * 256;
         if (rr < r1 && o < p.CO) {
           float f[8];
-          unpack_bf16x8(q[u][pg], f);
+          union { u32x4 v; uint4 s; } cv; cv.v = cur[u][pg];
+          unpack_bf16x8(cv.s, f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float v = f[e] * sc[pg][e] + sh[pg][e];

@@ -50,6 +50,17 @@ CONV_CASES = [
     (4, 8, 8, 64, 64, 3, 1, 0, 1, 1),          # 128x128 tile
     (4, 8, 8, 64, 64, 3, 1, 0, 5, 1),          # 128x64 tile
     (4, 8, 8, 64, 64, 3, 1, 0, 6, 2),          # 64x64 tile + split-K
+    # LDS-DMA variants (tiles 7..12): zero padding / ragged tails come from the zero page, swizzle on the source chunk
+    (2, 16, 16, 64, 64, 3, 1, 0, 7, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 8, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 10, 1),
+    (2, 16, 16, 128, 128, 3, 2, 0, 9, 1),
+    (2, 8, 8, 128, 128, 3, 1, 1, 9, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 12, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 11, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 9, 4),
+    (2, 16, 16, 192, 128, 1, 1, 0, 7, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 10, 1),     # full level-64 shape
 ]
 
 

@@ -70,6 +70,63 @@ class AttentionParams(Structure):
         ("o", c_void_p), ("o_stride_b", c_int64), ("o_stride_l", c_int64),
         ("B", c_int32), ("heads", c_int32), ("Lq", c_int32), ("Lk", c_int32),
         ("scale", c_float),
+        ("lse", c_void_p),
+    ]
+
+
+class GateBwdParams(Structure):
+    _fields_ = [
+        ("dy", c_void_p), ("lddy", c_int64), ("y0", c_void_p), ("ldy0", c_int64), ("dx", c_void_p), ("lddx", c_int64),
+        ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("groups", c_int32),
+        ("gate", c_void_p), ("gate_B", c_int32),
+        ("dgate_partial", c_void_p),
+    ]
+
+
+class GegluParams(Structure):
+    _fields_ = [
+        ("hg", c_void_p), ("ldhg", c_int64), ("out", c_void_p), ("ldout", c_int64),
+        ("dout", c_void_p), ("lddout", c_int64), ("dhg", c_void_p), ("lddhg", c_int64),
+        ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("groups", c_int32),
+        ("gate", c_void_p), ("gate_B", c_int32),
+        ("dgate_partial", c_void_p),
+        ("backward", c_int32),
+    ]
+
+
+class GroupNormBwdParams(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dx", c_void_p), ("lddx", c_int64),
+        ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("groups", c_int32),
+        ("gamma", c_void_p), ("beta", c_void_p),
+        ("eps", c_float), ("silu", c_int32),
+        ("fwd_stats", c_void_p),
+        ("workspace", c_void_p),
+    ]
+
+
+class LayerNormBwdParams(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dx", c_void_p), ("lddx", c_int64),
+        ("rows", c_int32), ("C", c_int32),
+        ("gamma", c_void_p),
+        ("eps", c_float),
+    ]
+
+
+class AttentionBwdParams(Structure):
+    _fields_ = [
+        ("q", c_void_p), ("q_stride_b", c_int64), ("q_stride_l", c_int64),
+        ("k", c_void_p), ("k_stride_b", c_int64), ("k_stride_l", c_int64),
+        ("v", c_void_p), ("v_stride_b", c_int64), ("v_stride_l", c_int64),
+        ("o", c_void_p), ("o_stride_b", c_int64), ("o_stride_l", c_int64),
+        ("dout", c_void_p), ("dout_stride_b", c_int64), ("dout_stride_l", c_int64),
+        ("dq", c_void_p), ("dq_stride_b", c_int64), ("dq_stride_l", c_int64),
+        ("dk", c_void_p), ("dk_stride_b", c_int64), ("dk_stride_l", c_int64),
+        ("dv", c_void_p), ("dv_stride_b", c_int64), ("dv_stride_l", c_int64),
+        ("lse", c_void_p), ("delta", c_void_p),
+        ("B", c_int32), ("heads", c_int32), ("Lq", c_int32), ("Lk", c_int32),
+        ("scale", c_float),
     ]
 
 
@@ -83,6 +140,11 @@ EXPORTS = [
     ("aptp_groupnorm_workspace_bytes", c_int64, [POINTER(GroupNormParams)]),
     ("aptp_layernorm", c_int, [POINTER(LayerNormParams), c_void_p]),
     ("aptp_attention", c_int, [POINTER(AttentionParams), c_void_p]),
+    ("aptp_gate_bwd", c_int, [POINTER(GateBwdParams), c_void_p]),
+    ("aptp_geglu", c_int, [POINTER(GegluParams), c_void_p]),
+    ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),
+    ("aptp_layernorm_bwd", c_int, [POINTER(LayerNormBwdParams), c_void_p]),
+    ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),
     ("aptp_last_error", c_char_p, []),
     ("aptp_version", c_int, []),
 ]

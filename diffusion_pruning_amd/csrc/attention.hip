@@ -19,6 +19,7 @@ struct AttnK {
   __bf16* o; int64_t osb, osl;
   int B, H, Lq, Lk;
   float c;   // scale * log2(e)
+  float* lse;   // optional [B, H, Lq]: log2-domain log-sum-exp of the scaled scores (for the backward pass)
 };
 
 // position of key offset o (0..15) inside its 16-key group of the V^T image: o = 8a + 4h + c  ->  8h + 4a + c
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
   // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------------
   const int qrow = q0 + lq;
   if (qrow < p.Lq) {
+    if (p.lse && hh == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run + log2f(l_run);
     const float inv = 1.0f / l_run;
     __bf16* op = p.o + (int64_t)b * p.osb + (int64_t)qrow * p.osl + (int64_t)h * 64;
 #pragma unroll
@@ -265,6 +267,7 @@ extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream
   k.o = (__bf16*)p->o; k.osb = p->o_stride_b; k.osl = p->o_stride_l;
   k.B = p->B; k.H = p->heads; k.Lq = p->Lq; k.Lk = p->Lk;
   k.c = p->scale * 1.44269504088896340736f;
+  k.lse = p->lse;
   dim3 grid((p->Lq + 127) / 128, p->heads, p->B);
   // split the key range over two wave groups when the query-parallel grid alone gives < 2 waves per SIMD
   const int64_t waves = (int64_t)grid.x * grid.y * grid.z * 4;

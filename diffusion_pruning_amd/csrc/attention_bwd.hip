@@ -1,0 +1,336 @@
+// Flash-style attention backward, head_dim 64, bf16 operands, fp32 accumulation (gfx950).
+//
+// With P = softmax(QK^T * scale) recomputed from the forward's log-sum-exp (no N x N tensor is stored):
+//   delta[q] = sum_d dO[q,d] * O[q,d]
+//   dV = P^T dO;   dP = dO V^T;   dS = P o (dP - delta);   dQ = scale * dS K;   dK = scale * dS^T Q
+// Three kernels, none of which needs a cross-workgroup reduction (deterministic):
+//   attn_delta_kernel   one thread per (b, q, head)
+//   attn_dq_kernel      workgroup = 128 queries (4 waves x 32), sweeps key tiles;   mirrors the forward's data flow
+//   attn_dkdv_kernel    workgroup = 128 keys (4 waves x 32), sweeps query tiles
+// MFMA operand plumbing is the forward kernel's: the "row on the lane" product is computed transposed
+// (mfma_f32_32x32x16_bf16 with the LDS tile as A operand and register-resident fragments as B operand), so each lane
+// owns ONE query (dQ kernel) or ONE key (dK/dV kernel) and the score accumulator, converted to bf16, is directly the
+// B operand of the following product; the transposed LDS images use the same 16-row permutation as the forward's V^T.
+#include "aptp_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct AttnBwdK {
+  const __bf16* q; int64_t qsb, qsl;
+  const __bf16* k; int64_t ksb, ksl;
+  const __bf16* v; int64_t vsb, vsl;
+  const __bf16* o; int64_t osb, osl;
+  const __bf16* dout; int64_t dosb, dosl;
+  __bf16* dq; int64_t dqsb, dqsl;
+  __bf16* dk; int64_t dksb, dksl;
+  __bf16* dv; int64_t dvsb, dvsl;
+  const float* lse; float* delta;   // [B, H, Lq]
+  int B, H, Lq, Lk;
+  float scale, c;                   // c = scale * log2(e)
+};
+
+__device__ __forceinline__ int perm16(int idx) {   // o = 8a + 4h + c  ->  8h + 4a + c inside each group of 16
+  const int o = idx & 15;
+  return (idx & ~15) | ((o & 4) << 1) | ((o & 8) >> 1) | (o & 3);
+}
+
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnBwdK p) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.Lq * p.H;
+  if (idx >= total) return;
+  const int h = (int)(idx % p.H);
+  const int64_t bq = idx / p.H;
+  const int q = (int)(bq % p.Lq), b = (int)(bq / p.Lq);
+  const __bf16* op = p.o + (int64_t)b * p.osb + (int64_t)q * p.osl + h * 64;
+  const __bf16* dp = p.dout + (int64_t)b * p.dosb + (int64_t)q * p.dosl + h * 64;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    union { u32x4 v; __bf16 e[8]; } a, d;
+    a.v = *reinterpret_cast<const u32x4*>(op + i * 8);
+    d.v = *reinterpret_cast<const u32x4*>(dp + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += (float)a.e[e] * (float)d.e[e];
+  }
+  p.delta[((int64_t)b * p.H + h) * p.Lq + q] = acc;
+}
+
+// stage a [64 rows][64 d] tile held as row pairs (2*pair, 2*pair+1; 16-byte chunk `chunk`) into
+//   rm: row-major image, chunks XOR-swizzled by (row>>1)&7      (A operand with rows on the MFMA row index)
+//   tr: transposed image [d][perm16(row)], chunks XOR-swizzled by (d>>1)&7   (A operand with d on the MFMA row index)
+__device__ __forceinline__ void stage_tile(__bf16* rm, __bf16* tr, const u32x4 r0, const u32x4 r1, int pair, int chunk) {
+  const int sw = chunk ^ (pair & 7);
+  if (rm) {
+    *reinterpret_cast<u32x4*>(rm + (2 * pair) * 64 + sw * 8) = r0;
+    *reinterpret_cast<u32x4*>(rm + (2 * pair + 1) * 64 + sw * 8) = r1;
+  }
+  if (tr) {
+    const int pos = perm16(2 * pair);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = chunk * 8 + e;
+      const int swt = (pos >> 3) ^ ((d >> 1) & 7);
+      const uint32_t a = r0[e >> 1], b = r1[e >> 1];
+      const uint32_t w = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+      *reinterpret_cast<uint32_t*>(tr + d * 64 + swt * 8 + (pos & 7)) = w;
+    }
+  }
+}
+
+__device__ __forceinline__ u32x4 load_row16(const __bf16* base, int64_t stride, int row, int nrows, int chunk) {
+  const int rc = row < nrows ? row : nrows - 1;
+  u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)rc * stride + chunk * 8);
+  return row < nrows ? v : (u32x4){0u, 0u, 0u, 0u};
+}
+
+// A-operand fragment of a row-major image: lane (row = base + lq, hh), k-step s -> chunk 2s + hh
+__device__ __forceinline__ bf16x8 frag_rm(const __bf16* img, int row, int s, int hh) {
+  const int sw = (2 * s + hh) ^ ((row >> 1) & 7);
+  return *reinterpret_cast<const bf16x8*>(img + row * 64 + sw * 8);
+}
+// A-operand fragment of a transposed image: lane (d = base + lq, hh), sub-tile t (32 rows), k-step s2 (16 rows)
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int d, int t, int s2, int hh) {
+  const int sw = (4 * t + 2 * s2 + hh) ^ ((d >> 1) & 7);
+  return *reinterpret_cast<const bf16x8*>(img + d * 64 + sw * 8);
+}
+
+__global__ __launch_bounds__(256) void attn_dq_kernel(const AttnBwdK p) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * 64], Kt[64 * 64], Vs[64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + lq;
+  const bool qok = qrow < p.Lq;
+  const int qc = qok ? qrow : p.Lq - 1;
+  const __bf16* qp = p.q + (int64_t)b * p.qsb + (int64_t)h * 64;
+  const __bf16* dop = p.dout + (int64_t)b * p.dosb + (int64_t)h * 64;
+  const __bf16* kp = p.k + (int64_t)b * p.ksb + (int64_t)h * 64;
+  const __bf16* vp = p.v + (int64_t)b * p.vsb + (int64_t)h * 64;
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    u32x4 a = *reinterpret_cast<const u32x4*>(qp + (int64_t)qc * p.qsl + 16 * s + 8 * hh);
+    u32x4 d = *reinterpret_cast<const u32x4*>(dop + (int64_t)qc * p.dosl + 16 * s + 8 * hh);
+    a = qok ? a : (u32x4){0u, 0u, 0u, 0u};
+    d = qok ? d : (u32x4){0u, 0u, 0u, 0u};
+    qf[s] = __builtin_bit_cast(bf16x8, a);
+    dof[s] = __builtin_bit_cast(bf16x8, d);
+  }
+  const int64_t sidx = ((int64_t)b * p.H + h) * p.Lq + qc;
+  const float lse = qok ? p.lse[sidx] : 0.f;
+  const float delta = qok ? p.delta[sidx] : 0.f;
+
+  const int chunk = tid & 7, pair = tid >> 3;
+  u32x4 kr[2], vr[2];
+  auto load_kv = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      kr[i] = load_row16(kp, p.ksl, tile * 64 + 2 * pair + i, p.Lk, chunk);
+      vr[i] = load_row16(vp, p.vsl, tile * 64 + 2 * pair + i, p.Lk, chunk);
+    }
+  };
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[u][r] = 0.f;
+
+  const int ntiles = (p.Lk + 63) / 64;
+  load_kv(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();
+    stage_tile(Ks, Kt, kr[0], kr[1], pair, chunk);
+    stage_tile(Vs, nullptr, vr[0], vr[1], pair, chunk);
+    __syncthreads();
+    if (tile + 1 < ntiles) load_kv(tile + 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Ks, 32 * t + lq, s, hh), qf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Vs, 32 * t + lq, s, hh), dof[s], dpacc, 0, 0, 0);
+      }
+      // sacc[r] = S^T[key = 64*tile + 32t + (r&3) + 8(r>>2) + 4hh][q]; rows past Lk hold K = 0, so their dS meets K^T = 0
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(sacc[r] * p.c - lse);
+        sacc[r] = pv * (dpacc[r] - delta);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 dsf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsf[j] = (__bf16)sacc[8 * s2 + j];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          dqacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, 32 * u + lq, t, s2, hh), dsf, dqacc[u], 0, 0, 0);
+      }
+    }
+  }
+  if (qok) {
+    __bf16* dqp = p.dq + (int64_t)b * p.dqsb + (int64_t)qrow * p.dqsl + (int64_t)h * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * u + 8 * g + 4 * hh;
+        uint2 w;
+        w.x = pack_bf16x2(dqacc[u][4 * g + 0] * p.scale, dqacc[u][4 * g + 1] * p.scale);
+        w.y = pack_bf16x2(dqacc[u][4 * g + 2] * p.scale, dqacc[u][4 * g + 3] * p.scale);
+        *reinterpret_cast<uint2*>(dqp + d) = w;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
+  __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * 64], Qt[64 * 64], Ds[64 * 64], Dt[64 * 64];
+  __shared__ __attribute__((aligned(16))) float lse_s[64], delta_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int krow = k0 + lk;
+  const bool kok = krow < p.Lk;
+  const int kc = kok ? krow : p.Lk - 1;
+  const __bf16* qp = p.q + (int64_t)b * p.qsb + (int64_t)h * 64;
+  const __bf16* dop = p.dout + (int64_t)b * p.dosb + (int64_t)h * 64;
+  const __bf16* kp = p.k + (int64_t)b * p.ksb + (int64_t)h * 64;
+  const __bf16* vp = p.v + (int64_t)b * p.vsb + (int64_t)h * 64;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    u32x4 a = *reinterpret_cast<const u32x4*>(kp + (int64_t)kc * p.ksl + 16 * s + 8 * hh);
+    u32x4 d = *reinterpret_cast<const u32x4*>(vp + (int64_t)kc * p.vsl + 16 * s + 8 * hh);
+    a = kok ? a : (u32x4){0u, 0u, 0u, 0u};
+    d = kok ? d : (u32x4){0u, 0u, 0u, 0u};
+    kf[s] = __builtin_bit_cast(bf16x8, a);
+    vf[s] = __builtin_bit_cast(bf16x8, d);
+  }
+  const int chunk = tid & 7, pair = tid >> 3;
+  u32x4 qr[2], dr[2];
+  float sreg = 0.f;
+  const float* lse_g = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  const float* delta_g = p.delta + ((int64_t)b * p.H + h) * p.Lq;
+  auto load_q = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      qr[i] = load_row16(qp, p.qsl, tile * 64 + 2 * pair + i, p.Lq, chunk);
+      dr[i] = load_row16(dop, p.dosl, tile * 64 + 2 * pair + i, p.Lq, chunk);
+    }
+    if (tid < 128) {
+      const int qi = tile * 64 + (tid & 63);
+      const int qic = qi < p.Lq ? qi : p.Lq - 1;
+      const float v = (tid < 64 ? lse_g : delta_g)[qic];
+      sreg = qi < p.Lq ? v : 0.f;
+    }
+  };
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkacc[u][r] = 0.f; dvacc[u][r] = 0.f; }
+
+  const int ntiles = (p.Lq + 63) / 64;
+  load_q(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();
+    stage_tile(Qs, Qt, qr[0], qr[1], pair, chunk);
+    stage_tile(Ds, Dt, dr[0], dr[1], pair, chunk);
+    if (tid < 64) lse_s[tid] = sreg;
+    else if (tid < 128) delta_s[tid - 64] = sreg;
+    __syncthreads();
+    if (tile + 1 < ntiles) load_q(tile + 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Qs, 32 * t + lk, s, hh), kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(Ds, 32 * t + lk, s, hh), vf[s], dpacc, 0, 0, 0);
+      }
+      // sacc[r] = S[q = 64*tile + 32t + (r&3) + 8(r>>2) + 4hh][key]; query rows past Lq hold Q = dO = 0, lse = delta = 0
+      f32x16 pacc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 32 * t + 8 * g + 4 * hh);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 32 * t + 8 * g + 4 * hh);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          const float pv = exp2f(sacc[r] * p.c - lv[i]);
+          pacc[r] = pv;
+          sacc[r] = pv * (dpacc[r] - dv[i]);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf, dsf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pf[j] = (__bf16)pacc[8 * s2 + j]; dsf[j] = (__bf16)sacc[8 * s2 + j]; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          dvacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Dt, 32 * u + lk, t, s2, hh), pf, dvacc[u], 0, 0, 0);
+          dkacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 32 * u + lk, t, s2, hh), dsf, dkacc[u], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (kok) {
+    __bf16* dkp = p.dk + (int64_t)b * p.dksb + (int64_t)krow * p.dksl + (int64_t)h * 64;
+    __bf16* dvp = p.dv + (int64_t)b * p.dvsb + (int64_t)krow * p.dvsl + (int64_t)h * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * u + 8 * g + 4 * hh;
+        uint2 w;
+        w.x = pack_bf16x2(dkacc[u][4 * g + 0] * p.scale, dkacc[u][4 * g + 1] * p.scale);
+        w.y = pack_bf16x2(dkacc[u][4 * g + 2] * p.scale, dkacc[u][4 * g + 3] * p.scale);
+        *reinterpret_cast<uint2*>(dkp + d) = w;
+        w.x = pack_bf16x2(dvacc[u][4 * g + 0], dvacc[u][4 * g + 1]);
+        w.y = pack_bf16x2(dvacc[u][4 * g + 2], dvacc[u][4 * g + 3]);
+        *reinterpret_cast<uint2*>(dvp + d) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int aptp_attention_bwd(const AptpAttentionBwdParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->q && p->k && p->v && p->o && p->dout && p->dq && p->dk && p->dv && p->lse && p->delta, "attention_bwd: null pointer");
+  APTP_CHECK(p->B > 0 && p->heads > 0 && p->Lq > 0 && p->Lk > 0 && p->heads <= 65535 && p->B <= 65535, "attention_bwd: bad extents");
+  const int64_t strides[] = {p->q_stride_b, p->q_stride_l, p->k_stride_b, p->k_stride_l, p->v_stride_b, p->v_stride_l,
+                             p->o_stride_b, p->o_stride_l, p->dout_stride_b, p->dout_stride_l, p->dq_stride_b, p->dq_stride_l,
+                             p->dk_stride_b, p->dk_stride_l, p->dv_stride_b, p->dv_stride_l};
+  for (int64_t s : strides) APTP_CHECK(s % 8 == 0, "attention_bwd: strides must be multiples of 8 elements");
+  const void* ptrs[] = {p->q, p->k, p->v, p->o, p->dout, p->dq, p->dk, p->dv};
+  for (const void* q : ptrs) APTP_CHECK(((uintptr_t)q % 16) == 0, "attention_bwd: pointers must be 16-byte aligned");
+  AttnBwdK k;
+  k.q = (const __bf16*)p->q; k.qsb = p->q_stride_b; k.qsl = p->q_stride_l;
+  k.k = (const __bf16*)p->k; k.ksb = p->k_stride_b; k.ksl = p->k_stride_l;
+  k.v = (const __bf16*)p->v; k.vsb = p->v_stride_b; k.vsl = p->v_stride_l;
+  k.o = (const __bf16*)p->o; k.osb = p->o_stride_b; k.osl = p->o_stride_l;
+  k.dout = (const __bf16*)p->dout; k.dosb = p->dout_stride_b; k.dosl = p->dout_stride_l;
+  k.dq = (__bf16*)p->dq; k.dqsb = p->dq_stride_b; k.dqsl = p->dq_stride_l;
+  k.dk = (__bf16*)p->dk; k.dksb = p->dk_stride_b; k.dksl = p->dk_stride_l;
+  k.dv = (__bf16*)p->dv; k.dvsb = p->dv_stride_b; k.dvsl = p->dv_stride_l;
+  k.lse = p->lse; k.delta = p->delta;
+  k.B = p->B; k.H = p->heads; k.Lq = p->Lq; k.Lk = p->Lk;
+  k.scale = p->scale; k.c = p->scale * 1.44269504088896340736f;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)p->B * p->Lq * p->heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
+  hipLaunchKernelGGL(attn_dq_kernel, dim3((p->Lq + 127) / 128, p->heads, p->B), dim3(256), 0, s, k);
+  hipLaunchKernelGGL(attn_dkdv_kernel, dim3((p->Lk + 127) / 128, p->heads, p->B), dim3(256), 0, s, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}

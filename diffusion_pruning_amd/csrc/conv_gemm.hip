@@ -19,7 +19,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct KParams {
   const __bf16* x; int64_t ldx;
-  int B, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, ups;
+  int B, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, ups;   // ups: right-shift applied to gather coordinates (0/1)
+  int zins;                 // 1: zero-insertion upsample (odd coordinates read zero) instead of nearest
   int HinE, WinE;           // effective (upsampled) input extent
   const __bf16* w; int N; int ncc; int nK; int64_t Ktot;   // ncc = cin_pad/64, nK = taps*ncc
   const float* bias; const float* rowbias; int ld_rowbias;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
-      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE;
+      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE && !(p.zins & (iy | ix));
       iy >>= p.ups; ix >>= p.ups;
       const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31 (checked on the host)
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ok ? off : OOB, 0, 0);
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
-      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE;
+      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE && !(p.zins & (iy | ix));
       iy >>= p.ups; ix >>= p.ups;
       const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31
       const uint64_t va = reinterpret_cast<uint64_t>(p.x) + off, vz = reinterpret_cast<uint64_t>(zsrc);
@@ -538,7 +539,7 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   APTP_CHECK(p->ldx % 8 == 0 && p->ldx >= p->Cin, "conv_gemm: ldx (%lld) must be a multiple of 8 and >= Cin", (long long)p->ldx);
   APTP_CHECK(p->N > 0 && p->N % 8 == 0, "conv_gemm: N (%d) must be a positive multiple of 8", p->N);
   APTP_CHECK(p->cin_pad % BK == 0 && p->cin_pad >= p->Cin && p->cin_pad < p->Cin + BK, "conv_gemm: cin_pad (%d) != ceil(Cin/64)*64", p->cin_pad);
-  APTP_CHECK(p->KH >= 1 && p->KW >= 1 && p->stride >= 1 && p->pad >= 0 && (p->ups == 0 || p->ups == 1), "conv_gemm: bad filter geometry");
+  APTP_CHECK(p->KH >= 1 && p->KW >= 1 && p->stride >= 1 && p->pad >= 0 && p->ups >= 0 && p->ups <= 2, "conv_gemm: bad filter geometry");
   APTP_CHECK(((uintptr_t)p->x % 16) == 0 && ((uintptr_t)p->w % 16) == 0 && ((uintptr_t)p->y % 8) == 0, "conv_gemm: pointer alignment");
   const int geglu = p->act == APTP_ACT_GEGLU;
   APTP_CHECK(!geglu || p->N % 32 == 0, "conv_gemm: GEGLU needs N %% 32 == 0");
@@ -553,12 +554,13 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   const int64_t M64 = (int64_t)p->B * p->Hout * p->Wout;
   APTP_CHECK(M64 < (1ll << 31), "conv_gemm: M too large");
   // geometry consistency: every output pixel's centre tap must map inside the (upsampled) input
-  const int HinE = p->Hin << p->ups, WinE = p->Win << p->ups;
+  const int sh = p->ups ? 1 : 0;   // ups 1 = nearest x2, ups 2 = zero-insertion x2 (both double the gather extent)
+  const int HinE = p->Hin << sh, WinE = p->Win << sh;
   APTP_CHECK(p->Hout == (HinE + 2 * p->pad - p->KH) / p->stride + 1 && p->Wout == (WinE + 2 * p->pad - p->KW) / p->stride + 1,
              "conv_gemm: Hout/Wout inconsistent with input extent, filter, stride and padding");
   k.x = (const __bf16*)p->x; k.ldx = p->ldx;
   k.B = p->B; k.Hin = p->Hin; k.Win = p->Win; k.Cin = p->Cin; k.Hout = p->Hout; k.Wout = p->Wout;
-  k.KH = p->KH; k.KW = p->KW; k.stride = p->stride; k.pad = p->pad; k.ups = p->ups;
+  k.KH = p->KH; k.KW = p->KW; k.stride = p->stride; k.pad = p->pad; k.ups = sh; k.zins = p->ups == 2 ? 1 : 0;
   k.HinE = HinE; k.WinE = WinE;
   k.w = (const __bf16*)p->w; k.N = p->N; k.ncc = p->cin_pad / BK; k.nK = p->KH * p->KW * k.ncc;
   k.Ktot = (int64_t)k.nK * BK;

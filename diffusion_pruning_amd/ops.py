@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionParams, ConvGemmParams, GroupNormParams, LayerNormParams
+from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, GateBwdParams,
+                   GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams)
 
 BK = 64
 
@@ -185,7 +186,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         raise ValueError(f"conv_gemm: x has {Cx} channels, packed weight expects {pw.Cin}")
     if pad is None:
         pad = pw.KH // 2
-    HinE, WinE = Hin << ups, Win << ups
+    sh = 1 if ups else 0            # ups 1 = nearest x2, ups 2 = zero-insertion x2 (dgrad of a stride-2 conv)
+    HinE, WinE = Hin << sh, Win << sh
     Hout = (HinE + 2 * pad - pw.KH) // stride + 1
     Wout = (WinE + 2 * pad - pw.KW) // stride + 1
     if pw.geglu:
@@ -260,8 +262,9 @@ def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
-              C: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """GroupNorm(+SiLU) of a [B,H,W,Cp] tensor over its first C real channels (Cp = roundup8(C))."""
+              C: Optional[int] = None, out: Optional[torch.Tensor] = None, keep_stats: bool = False):
+    """GroupNorm(+SiLU) of a [B,H,W,Cp] tensor over its first C real channels (Cp = roundup8(C)).
+    keep_stats: also return the fp32 [B, nchunk, groups, 2] statistics partials (needed by groupnorm_bwd)."""
     lib = _lib.load()
     _check_act(x, "groupnorm x")
     B, H, W, Cp = x.shape
@@ -274,10 +277,13 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
     p.x, p.ldx, p.y, p.ldy = x.data_ptr(), _ld(x), out.data_ptr(), _ld(out)
     p.B, p.HW, p.C, p.groups = B, H * W, C, groups
     p.gamma, p.beta, p.eps, p.silu = gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
-    ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
+    if keep_stats:
+        ws = torch.empty(B, lib.aptp_groupnorm_nchunk(H * W), groups, 2, dtype=torch.float32, device=x.device)
+    else:
+        ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
     p.workspace = ws.data_ptr()
     _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
-    return out
+    return (out, ws) if keep_stats else out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
@@ -299,7 +305,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale) v with head_dim 64.  q [B, Lq, >=heads*64], k/v [B, Lk, >=heads*64] are bf16 views
     (e.g. column slices of a fused QKV buffer); heads are laid out as consecutive 64-wide column blocks."""
     lib = _lib.load()
@@ -316,5 +322,134 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     p.o, p.o_stride_b, p.o_stride_l = out.data_ptr(), out.stride(0), out.stride(1)
     p.B, p.heads, p.Lq, p.Lk = B, heads, Lq, Lk
     p.scale = (1.0 / 8.0) if scale is None else scale
+    if lse is not None:
+        assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (B, heads, Lq)
+        p.lse = lse.data_ptr()
     _lib.check(lib.aptp_attention(ctypes.byref(p), _stream()), "aptp_attention")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# backward-path wrappers
+# ------------------------------------------------------------------------------------------------------------------
+def pack_weight_dgrad(w: torch.Tensor, device=None) -> PackedWeight:
+    """Packed weights of the data-gradient contraction: OIHW -> IOHW with the filter rotated by 180 degrees
+    (a linear weight [out,in] -> its transpose)."""
+    if w.dim() == 2:
+        return pack_weight(w.detach().t().contiguous(), None, device=device)
+    return pack_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous(), None, device=device)
+
+
+def _rows(t: torch.Tensor):
+    """[B, H, W, C] or [B, L, C] -> (B, rows per sample, C, ld)"""
+    if t.dim() == 4:
+        return t.shape[0], t.shape[1] * t.shape[2], t.shape[3], _ld(t)
+    B, L, C = t.shape
+    return B, L, C, (t.stride(1) if L > 1 else max(t.stride(1), C))
+
+
+def gate_bwd(dy: torch.Tensor, y0: torch.Tensor, gate: torch.Tensor):
+    """dx = dy * gate (expanded over channel groups, batch tiled), dgate [Bg, G] = sum dy*y0 (fp32)."""
+    lib = _lib.load()
+    B, HW, C, lddy = _rows(dy)
+    _, _, _, ldy0 = _rows(y0)
+    assert dy.dtype == torch.bfloat16 and y0.dtype == torch.bfloat16 and dy.shape == y0.shape
+    gate = gate.detach().to(dtype=torch.float32).contiguous()
+    Bg, G = gate.shape
+    dx = torch.empty_like(dy, memory_format=torch.contiguous_format)
+    nchunk = lib.aptp_groupnorm_nchunk(HW)
+    part = torch.empty(B, nchunk, G, dtype=torch.float32, device=dy.device)
+    p = GateBwdParams()
+    p.dy, p.lddy, p.y0, p.ldy0, p.dx, p.lddx = dy.data_ptr(), lddy, y0.data_ptr(), ldy0, dx.data_ptr(), C
+    p.B, p.HW, p.C, p.groups = B, HW, C, G
+    p.gate, p.gate_B, p.dgate_partial = gate.data_ptr(), Bg, part.data_ptr()
+    _lib.check(lib.aptp_gate_bwd(ctypes.byref(p), _stream()), "aptp_gate_bwd")
+    dgate = part.sum(dim=1).view(B // Bg, Bg, G).sum(dim=0)
+    return dx, dgate
+
+
+def geglu_fwd(hg: torch.Tensor, gate: Optional[torch.Tensor]) -> torch.Tensor:
+    lib = _lib.load()
+    B, HW, C2, ld = _rows(hg)
+    C = C2 // 2
+    out = torch.empty(*hg.shape[:-1], C, dtype=torch.bfloat16, device=hg.device)
+    p = GegluParams()
+    p.hg, p.ldhg, p.out, p.ldout = hg.data_ptr(), ld, out.data_ptr(), C
+    p.B, p.HW, p.C = B, HW, C
+    if gate is not None:
+        gate = gate.detach().to(dtype=torch.float32).contiguous()
+        p.gate, p.gate_B, p.groups = gate.data_ptr(), gate.shape[0], gate.shape[1]
+    else:
+        p.groups = 32 if C % 32 == 0 else 1
+    p.backward = 0
+    _lib.check(lib.aptp_geglu(ctypes.byref(p), _stream()), "aptp_geglu")
+    return out
+
+
+def geglu_bwd(hg: torch.Tensor, dout: torch.Tensor, gate: Optional[torch.Tensor]):
+    lib = _lib.load()
+    B, HW, C2, ld = _rows(hg)
+    C = C2 // 2
+    _, _, _, lddout = _rows(dout)
+    dhg = torch.empty(*hg.shape, dtype=torch.bfloat16, device=hg.device)
+    p = GegluParams()
+    p.hg, p.ldhg, p.dout, p.lddout, p.dhg, p.lddhg = hg.data_ptr(), ld, dout.data_ptr(), lddout, dhg.data_ptr(), C2
+    p.B, p.HW, p.C = B, HW, C
+    Bg, G = (gate.shape if gate is not None else (1, 32 if C % 32 == 0 else 1))
+    if gate is not None:
+        gate = gate.detach().to(dtype=torch.float32).contiguous()
+        p.gate, p.gate_B = gate.data_ptr(), Bg
+    p.groups = G
+    part = torch.empty(B, lib.aptp_groupnorm_nchunk(HW), G, dtype=torch.float32, device=hg.device)
+    p.dgate_partial = part.data_ptr()
+    p.backward = 1
+    _lib.check(lib.aptp_geglu(ctypes.byref(p), _stream()), "aptp_geglu(bwd)")
+    dgate = part.sum(dim=1).view(B // Bg, Bg, G).sum(dim=0) if gate is not None else None
+    return dhg, dgate
+
+
+def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                  silu: bool, stats: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    B, HW, C, ldx = _rows(x)
+    _, _, _, lddy = _rows(dy)
+    dx = torch.empty(*x.shape, dtype=torch.bfloat16, device=x.device)
+    p = GroupNormBwdParams()
+    p.x, p.ldx, p.dy, p.lddy, p.dx, p.lddx = x.data_ptr(), ldx, dy.data_ptr(), lddy, dx.data_ptr(), C
+    p.B, p.HW, p.C, p.groups = B, HW, C, groups
+    p.gamma, p.beta, p.eps, p.silu = gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
+    p.fwd_stats = stats.data_ptr()
+    ws = torch.empty_like(stats)
+    p.workspace = ws.data_ptr()
+    _lib.check(lib.aptp_groupnorm_bwd(ctypes.byref(p), _stream()), "aptp_groupnorm_bwd")
+    return dx
+
+
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    lib = _lib.load()
+    B, L, C, ldx = _rows(x)
+    _, _, _, lddy = _rows(dy)
+    dx = torch.empty(*x.shape, dtype=torch.bfloat16, device=x.device)
+    p = LayerNormBwdParams()
+    p.x, p.ldx, p.dy, p.lddy, p.dx, p.lddx = x.data_ptr(), ldx, dy.data_ptr(), lddy, dx.data_ptr(), C
+    p.rows, p.C, p.gamma, p.eps = B * L, C, gamma.data_ptr(), eps
+    _lib.check(lib.aptp_layernorm_bwd(ctypes.byref(p), _stream()), "aptp_layernorm_bwd")
+    return dx
+
+
+def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional[float] = None):
+    """dq/dk/dv are preallocated bf16 views (e.g. column slices of one fused gradient buffer), written in place."""
+    lib = _lib.load()
+    B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+    delta = torch.empty(B, heads, Lq, dtype=torch.float32, device=q.device)
+    p = AttentionBwdParams()
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1 and t.shape[2] == heads * 64, name
+        setattr(p, name, t.data_ptr())
+        setattr(p, name + "_stride_b", t.stride(0))
+        setattr(p, name + "_stride_l", t.stride(1))
+    p.lse, p.delta = lse.data_ptr(), delta.data_ptr()
+    p.B, p.heads, p.Lq, p.Lk = B, heads, Lq, Lk
+    p.scale = (1.0 / 8.0) if scale is None else scale
+    _lib.check(lib.aptp_attention_bwd(ctypes.byref(p), _stream()), "aptp_attention_bwd")
+    return dq, dk, dv

@@ -37,7 +37,9 @@ enum { APTP_ACT_NONE = 0, APTP_ACT_SILU = 1, APTP_ACT_GEGLU = 2 };
 
 /*
  * Implicit-GEMM convolution / linear:  y[m, n] = epilogue( sum_{tap,c} x[pix(m,tap), c] * w[n, tap, c] )
- *   m = (b, oy, ox) over B*Hout*Wout,  pix = (b, (oy*stride - pad + ky) >> ups, (ox*stride - pad + kx) >> ups)
+ *   m = (b, oy, ox) over B*Hout*Wout,  pix = (b, (oy*stride - pad + ky) >> u, (ox*stride - pad + kx) >> u)
+ *   ups = 0: u = 0;  ups = 1: u = 1 (nearest x2 upsample folded into the gather);  ups = 2: u = 1 and odd coordinates read
+ *   zero (zero-insertion x2 = the data-gradient of a stride-2 convolution, with flipped/transposed packed weights)
  * Replaces: F.conv2d in ResnetBlock2D*.conv1/conv2/conv_shortcut (pdm/models/unet/blocks.py:331,362,364-367,
  * 537,568,570-573), Downsample2D/Upsample2D convs (inherited diffusers; nearest-x2 folded via `ups`),
  * conv_in/conv_out (pdm/models/unet/unet_2d_conditional.py:1614,1721), and every F.linear of the transformer
@@ -145,9 +147,87 @@ typedef struct {
   void* o; int64_t o_stride_b, o_stride_l;
   int32_t B, heads, Lq, Lk;
   float scale;
+  float* lse;   /* optional fp32 [B, heads, Lq]: log2-domain log-sum-exp of the scaled scores, consumed by aptp_attention_bwd */
 } AptpAttentionParams;
 
 int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Backward path (data gradients + gate gradients; the U-Net weights are frozen in APTP's pruning step,
+ * pdm/training/trainer.py:742,827-829).  Data gradients of convolutions / linears reuse aptp_conv_gemm with
+ * flipped-transposed packed weights (ups = 2 for the stride-2 downsamplers).  What autograd derives in the reference
+ * from F.group_norm / F.silu / F.layer_norm / F.gelu / SDPA / the gate multiplies (blocks.py:41-50,250-260,296-359,
+ * 782-821; gates.py:15-21) is implemented by the entry points below.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* Width-gate backward: dx = dy * gate[b % gate_B, c / (C/groups)];  dgate_partial[b, chunk, g] = sum over the rows of the
+ * chunk and the channels of group g of dy * y0 (y0 = the pre-gate activation).  nchunk = aptp_groupnorm_nchunk(HW); the caller
+ * sums the chunk axis (and the CFG-tiled batch rows that share a gate row). */
+typedef struct {
+  const void* dy; int64_t lddy;   /* bf16 [B*HW, C] */
+  const void* y0; int64_t ldy0;   /* bf16 [B*HW, C] */
+  void* dx; int64_t lddx;         /* bf16 [B*HW, C] */
+  int32_t B, HW, C, groups;
+  const float* gate; int32_t gate_B;   /* fp32 [gate_B, groups] */
+  float* dgate_partial;                /* fp32 [B, nchunk, groups] */
+} AptpGateBwdParams;
+int aptp_gate_bwd(const AptpGateBwdParams* p, aptp_stream_t stream);
+
+/* GEGLU in its training form (value | gate halves side by side, not interleaved): forward out = (h*m) * gelu_erf(g*m);
+ * backward (backward = 1): dhg = [dh | dg], dgate_partial[b, chunk, grp] (blocks.py:41-50 through autograd). */
+typedef struct {
+  const void* hg; int64_t ldhg;        /* bf16 [B*HW, 2C] : h = cols [0,C), g = cols [C,2C) */
+  void* out; int64_t ldout;            /* bf16 [B*HW, C]  (forward) */
+  const void* dout; int64_t lddout;    /* bf16 [B*HW, C]  (backward) */
+  void* dhg; int64_t lddhg;            /* bf16 [B*HW, 2C] (backward) */
+  int32_t B, HW, C, groups;
+  const float* gate; int32_t gate_B;   /* fp32 [gate_B, groups] or NULL (mask == 1) */
+  float* dgate_partial;                /* fp32 [B, nchunk, groups] (backward) */
+  int32_t backward;
+} AptpGegluParams;
+int aptp_geglu(const AptpGegluParams* p, aptp_stream_t stream);
+
+/* GroupNorm(+SiLU) data gradient.  fwd_stats = the [B, nchunk, groups, 2] (sum, sumsq) partials the forward wrote into its
+ * workspace (keep that buffer alive); workspace: fp32 [B, nchunk, groups, 2]. */
+typedef struct {
+  const void* x; int64_t ldx;
+  const void* dy; int64_t lddy;
+  void* dx; int64_t lddx;
+  int32_t B, HW, C, groups;
+  const float* gamma; const float* beta;
+  float eps; int32_t silu;
+  const float* fwd_stats;
+  void* workspace;
+} AptpGroupNormBwdParams;
+int aptp_groupnorm_bwd(const AptpGroupNormBwdParams* p, aptp_stream_t stream);
+
+/* LayerNorm data gradient (statistics recomputed from x in registers). */
+typedef struct {
+  const void* x; int64_t ldx;
+  const void* dy; int64_t lddy;
+  void* dx; int64_t lddx;
+  int32_t rows, C;
+  const float* gamma;
+  float eps;
+} AptpLayerNormBwdParams;
+int aptp_layernorm_bwd(const AptpLayerNormBwdParams* p, aptp_stream_t stream);
+
+/* Attention backward: dq, dk, dv from q, k, v, o, dout and the forward's lse; delta is fp32 scratch [B, heads, Lq].
+ * Same strided [B, L, heads, 64] layout convention as aptp_attention. */
+typedef struct {
+  const void* q; int64_t q_stride_b, q_stride_l;
+  const void* k; int64_t k_stride_b, k_stride_l;
+  const void* v; int64_t v_stride_b, v_stride_l;
+  const void* o; int64_t o_stride_b, o_stride_l;
+  const void* dout; int64_t dout_stride_b, dout_stride_l;
+  void* dq; int64_t dq_stride_b, dq_stride_l;
+  void* dk; int64_t dk_stride_b, dk_stride_l;
+  void* dv; int64_t dv_stride_b, dv_stride_l;
+  const float* lse; float* delta;
+  int32_t B, heads, Lq, Lk;
+  float scale;
+} AptpAttentionBwdParams;
+int aptp_attention_bwd(const AptpAttentionBwdParams* p, aptp_stream_t stream);
 
 const char* aptp_last_error(void);
 int aptp_version(void);

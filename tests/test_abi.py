@@ -41,7 +41,10 @@ def test_every_declared_symbol_is_exported(lib):
 def test_ctypes_layout_matches_the_c_header():
     from diffusion_pruning_amd import _lib
     structs = {"AptpConvGemmParams": _lib.ConvGemmParams, "AptpGroupNormParams": _lib.GroupNormParams,
-               "AptpLayerNormParams": _lib.LayerNormParams, "AptpAttentionParams": _lib.AttentionParams}
+               "AptpLayerNormParams": _lib.LayerNormParams, "AptpAttentionParams": _lib.AttentionParams,
+               "AptpGateBwdParams": _lib.GateBwdParams, "AptpGegluParams": _lib.GegluParams,
+               "AptpGroupNormBwdParams": _lib.GroupNormBwdParams, "AptpLayerNormBwdParams": _lib.LayerNormBwdParams,
+               "AptpAttentionBwdParams": _lib.AttentionBwdParams}
     body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, cls in structs.items():
         body.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1,0 +1,152 @@
+"""GPU parity of the backward kernels (through the C ABI) against PyTorch fp32 autograd on the same bf16-rounded
+operands.  Tolerance: rel-L2 <= 8e-3 per op (bf16 operands and bf16 gradient outputs; attention recomputes P in bf16)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 8e-3
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    from diffusion_pruning_amd import ops as o
+    o._lib.load()
+    return o
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 96, 3, 1, 0), (2, 16, 16, 64, 64, 3, 2, 0), (2, 8, 8, 64, 64, 3, 1, 1),
+                                  (2, 8, 8, 192, 128, 1, 1, 0), (1, 8, 8, 320, 640, 3, 1, 0)])
+def test_conv_dgrad(ops, cuda, case):
+    B, H, W, Cin, Cout, k, stride, ups = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float().requires_grad_()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16().float()
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    y = F.conv2d(xin, w, None, stride=stride, padding=k // 2)
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    pwb = ops.pack_weight_dgrad(w, device=cuda)
+    dyd = nhwc(dy).bfloat16().to(cuda)
+    if stride == 2:
+        dx = ops.conv_gemm(dyd, pwb, stride=1, pad=k - 1 - k // 2, ups=2)
+    else:
+        dx = ops.conv_gemm(dyd, pwb, stride=1, pad=k - 1 - k // 2)
+        if ups:
+            Bq, H2, W2, C = dx.shape
+            dx = dx.float().view(Bq, H2 // 2, 2, W2 // 2, 2, C).sum(dim=(2, 4))
+    got = dx.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == x.grad.shape
+    assert rel_l2(got, x.grad) <= TOL
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 32, True, 1e-5), (2, 16, 16, 320, 32, True, 1e-5), (1, 8, 8, 2560, 32, True, 1e-5),
+                                  (2, 8, 8, 128, 32, False, 1e-6)])
+def test_groupnorm_bwd(ops, cuda, case):
+    B, H, W, C, G, silu, eps = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3).bfloat16().float().requires_grad_()
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.3 * torch.randn(C, generator=g)
+    y = F.group_norm(x, G, gamma, beta, eps)
+    if silu:
+        y = F.silu(y)
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    xd = nhwc(x.detach()).bfloat16().to(cuda)
+    yk, stats = ops.groupnorm(xd, gamma.to(cuda), beta.to(cuda), G, eps, silu, keep_stats=True)
+    assert rel_l2(yk.float().cpu().permute(0, 3, 1, 2), y.detach()) <= 4e-3
+    dx = ops.groupnorm_bwd(xd, nhwc(dy).bfloat16().to(cuda), gamma.to(cuda), beta.to(cuda), G, eps, silu, stats)
+    assert rel_l2(dx.float().cpu().permute(0, 3, 1, 2), x.grad) <= TOL
+
+
+@pytest.mark.parametrize("rows,C", [(33, 64), (128, 320), (65, 1280)])
+def test_layernorm_bwd(ops, cuda, rows, C):
+    g = torch.Generator().manual_seed(rows * C)
+    x = (torch.randn(1, rows, C, generator=g) * 1.5 + 0.4).bfloat16().float().requires_grad_()
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.3 * torch.randn(C, generator=g)
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    dx = ops.layernorm_bwd(x.detach().bfloat16().to(cuda), dy.bfloat16().to(cuda), gamma.to(cuda), 1e-5)
+    assert rel_l2(dx.float().cpu(), x.grad) <= TOL
+
+
+def test_gate_bwd_and_apply(ops, cuda):
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C, G = 4, 8, 8, 64, 32
+    y0 = torch.randn(B, H, W, C, generator=g).bfloat16().float()
+    gate = torch.rand(2, G, generator=g).requires_grad_()
+    mask = gate.repeat_interleave(C // G, dim=1).repeat(2, 1)[:, None, None, :]
+    y1 = y0 * mask
+    dy1 = torch.randn(y1.shape, generator=g).bfloat16().float()
+    y1.backward(dy1)
+    dx, dgate = ops.gate_bwd(dy1.bfloat16().to(cuda), y0.bfloat16().to(cuda), gate.detach().to(cuda))
+    assert rel_l2(dx.float().cpu(), dy1 * mask.detach()) <= 4e-3
+    assert rel_l2(dgate.cpu(), gate.grad) <= 2e-3
+    # the same kernel doubles as the forward gate multiply (dy := y0)
+    fwd, _ = ops.gate_bwd(y0.bfloat16().to(cuda), y0.bfloat16().to(cuda), gate.detach().to(cuda))
+    assert rel_l2(fwd.float().cpu(), y1.detach()) <= 4e-3
+
+
+@pytest.mark.parametrize("use_gate", [True, False])
+def test_geglu_fwd_bwd(ops, cuda, use_gate):
+    g = torch.Generator().manual_seed(5)
+    B, L, C = 2, 40, 256
+    hg = torch.randn(B, L, 2 * C, generator=g).bfloat16().float().requires_grad_()
+    gate = torch.rand(2, 32, generator=g).requires_grad_() if use_gate else None
+    h, gg = hg.chunk(2, dim=-1)
+    if use_gate:
+        m = gate.repeat_interleave(C // 32, dim=1)[:, None, :]
+        out = (h * m) * F.gelu(gg * m)
+    else:
+        out = h * F.gelu(gg)
+    dout = torch.randn(out.shape, generator=g).bfloat16().float()
+    out.backward(dout)
+    gd = gate.detach().to(cuda) if use_gate else None
+    hgd = hg.detach().bfloat16().to(cuda)
+    o = ops.geglu_fwd(hgd, gd)
+    assert rel_l2(o.float().cpu(), out.detach()) <= 4e-3
+    dhg, dgate = ops.geglu_bwd(hgd, dout.bfloat16().to(cuda), gd)
+    assert rel_l2(dhg.float().cpu(), hg.grad) <= TOL
+    if use_gate:
+        assert rel_l2(dgate.cpu(), gate.grad) <= 3e-3
+
+
+@pytest.mark.parametrize("case", [(1, 1, 64, 64), (2, 2, 256, 256), (2, 3, 200, 77), (1, 2, 1024, 1024), (1, 2, 100, 130)])
+def test_attention_bwd(ops, cuda, case):
+    B, h, Lq, Lk = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    q = torch.randn(B, Lq, h * 64, generator=g).bfloat16().float().requires_grad_()
+    k = torch.randn(B, Lk, h * 64, generator=g).bfloat16().float().requires_grad_()
+    v = torch.randn(B, Lk, h * 64, generator=g).bfloat16().float().requires_grad_()
+
+    def heads(t, L):
+        return t.view(B, L, h, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(heads(q, Lq), heads(k, Lk), heads(v, Lk)).transpose(1, 2).reshape(B, Lq, h * 64)
+    do = torch.randn(o.shape, generator=g).bfloat16().float()
+    o.backward(do)
+    qd, kd, vd = (t.detach().bfloat16().to(cuda) for t in (q, k, v))
+    lse = torch.empty(B, h, Lq, dtype=torch.float32, device=cuda)
+    od = ops.attention(qd, kd, vd, h, lse=lse)
+    assert rel_l2(od.float().cpu(), o.detach()) <= 6e-3
+    # lse is log2-domain of the scaled scores
+    s = (heads(q.detach(), Lq) @ heads(k.detach(), Lk).transpose(-1, -2)) / 8.0
+    assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1) * math.log2(math.e), atol=2e-2, rtol=1e-3)
+    dq, dk, dv = (torch.empty_like(t) for t in (qd, kd, vd))
+    ops.attention_bwd(qd, kd, vd, od, do.bfloat16().to(cuda), lse, h, dq, dk, dv)
+    assert rel_l2(dv.float().cpu(), v.grad) <= 1e-2
+    assert rel_l2(dq.float().cpu(), q.grad) <= 1.5e-2
+    assert rel_l2(dk.float().cpu(), k.grad) <= 1.5e-2

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     const float m = fmaxf(m_run, m1);
     const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);      // m_run is finite (group 0 always owns >= 1 tile)
     l_run = l_run * a0 + l1 * a1;
+    m_run = m;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll

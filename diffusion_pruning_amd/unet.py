@@ -152,15 +152,16 @@ class ResnetBlock2DWidthGated(nn.Module):
         m = self.gate.hard_uniform()
         return None if m is None else tuple(int(v) for v in m.tolist())
 
-    def plan(self, device) -> dict:
-        """Packed (and, for a hard batch-shared mask, compacted) weights for the current gate value."""
-        key = (self._mask_key(), self.semantics, str(device))
+    def plan(self, device, force_dense: bool = False) -> dict:
+        """Packed (and, for a hard batch-shared mask, compacted) weights for the current gate value.
+        force_dense: ignore the mask (full weights) — the autograd path needs the gate as an explicit multiply."""
+        key = (None if force_dense else self._mask_key(), self.semantics, str(device))
         pl = self._plans.get(key)
         if pl is not None:
             return pl
         if len(self._plans) >= 4:
             self._plans.pop(next(iter(self._plans)))
-        mask = self.gate.hard_uniform()
+        mask = None if force_dense else self.gate.hard_uniform()
         cg = self.out_channels // self.groups
         pl = {"compact": mask is not None and not bool((mask == 1).all())}
         dev = device
@@ -209,8 +210,53 @@ class ResnetBlock2DWidthGated(nn.Module):
     def _depth_state(self):
         return None, None   # (hard value or None, tensor or None)
 
+    def _needs_autograd(self, x) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        req = x.requires_grad or self.gate.gate_f.requires_grad
+        if self.depth_gated:
+            req = req or self.depth_gate.gate_f.requires_grad
+        return bool(req)
+
+    def _bwd_pack(self, pl, name, param, dev):
+        def get():
+            key = name + "_bwd"
+            if key not in pl:
+                pl[key] = ops.pack_weight_dgrad(param.detach(), device=dev)
+            return pl[key]
+        return get
+
+    def _forward_train(self, x, temb):
+        """Differentiable path (pruning step): same op order, gates as explicit multiplies, HIP forward + backward."""
+        from . import autograd as AG
+        dev = x.device
+        pl = self.plan(dev, force_dense=True)
+        B, H, W, Cin = x.shape
+        x_in = x[..., :Cin - self.skip_connection_dim] if (self.depth_gated and self.is_input_concatenated) else x
+        if self.depth_gated and self.dropped:
+            return _nchw(x_in)
+        a1 = AG.GroupNormFn.apply(x, pl["g1"], pl["b1"], self.groups, self.eps, True)
+        rowbias = self._temb_rowbias(temb, pl, B)
+        if rowbias.shape[1] != pl["w1"].N:            # bundle was built for a compacted plan: project locally
+            rowbias = self._temb_rowbias(TembBundle(emb_silu=temb.emb_silu), pl, B)
+        h = AG.conv(a1, pl["w1"], self._bwd_pack(pl, "w1", self.conv1.weight, dev), rowbias=rowbias)
+        gate = self.gate.gate_f
+        if gate.requires_grad or self.gate.hard_uniform() is None or not bool((self.gate.hard_uniform() == 1).all()):
+            h = AG.GateFn.apply(h, gate.to(device=dev, dtype=torch.float32))
+        a2 = AG.GroupNormFn.apply(h, pl["g2"], pl["b2"], self.groups, self.eps, True)
+        sc = x if pl["wsc"] is None else AG.conv(x, pl["wsc"], self._bwd_pack(pl, "wsc", self.conv_shortcut.weight if self.conv_shortcut is not None else None, dev), pad=0)
+        out = AG.conv(a2, pl["w2"], self._bwd_pack(pl, "w2", self.conv2.weight, dev)) + sc
+        if self.depth_gated:
+            d = self.depth_gate.gate_f
+            d_hard, _ = self._depth_state()
+            if d.requires_grad or d_hard != 1.0:
+                out = AG.depth_lerp(x_in, out, d.to(device=dev, dtype=torch.float32))
+        return _nchw(out)
+
     def forward(self, input_tensor: torch.Tensor, temb, scale: float = 1.0):
         x = _nhwc(input_tensor)
+        if self._needs_autograd(x):
+            return self._forward_train(x, temb)
         dev = x.device
         pl = self.plan(dev)
         B, H, W, Cin = x.shape
@@ -397,8 +443,8 @@ class Transformer2DModelWidthGated(nn.Module):
             out.append(None if m is None else tuple(int(v) for v in m.tolist()))
         return tuple(out)
 
-    def plan(self, device) -> dict:
-        key = (self._keys(), str(device))
+    def plan(self, device, force_dense: bool = False) -> dict:
+        key = ((None, None, None) if force_dense else self._keys(), str(device))
         pl = self._plans.get(key)
         if pl is not None:
             return pl
@@ -413,7 +459,7 @@ class Transformer2DModelWidthGated(nn.Module):
         for i, n in enumerate((tb.norm1, tb.norm2, tb.norm3)):
             pl[f"ln{i + 1}_g"], pl[f"ln{i + 1}_b"] = _f32(n.weight).to(dev), _f32(n.bias).to(dev)
         for name, attn in (("a1", tb.attn1), ("a2", tb.attn2)):
-            mask = attn.gate.hard_uniform()
+            mask = None if force_dense else attn.gate.hard_uniform()
             compact = mask is not None and not bool((mask == 1).all())
             if mask is not None and float(mask.sum()) == 0:
                 raise ValueError("head gate with no live head (the reference forbids it: non_zero_width)")
@@ -432,7 +478,7 @@ class Transformer2DModelWidthGated(nn.Module):
             pl[name + "_o"] = ops.pack_weight(attn.to_out[0].weight.detach(), attn.to_out[0].bias.detach(),
                                               in_idx=live, device=dev)
         geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
-        mask = geglu.gate.hard_uniform()
+        mask = None if force_dense else geglu.gate.hard_uniform()
         compact = mask is not None and not bool((mask == 1).all())
         if mask is not None and float(mask.sum()) == 0:
             raise ValueError("FF gate with no live chunk (the reference forbids it: non_zero_width)")
@@ -456,6 +502,82 @@ class Transformer2DModelWidthGated(nn.Module):
             g = g.repeat(1, rep)
         return g.contiguous()
 
+    # ---- differentiable path ---------------------------------------------------------------------------------------
+    def _needs_autograd(self, x) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        tb = self.transformer_blocks[0]
+        req = x.requires_grad or tb.attn1.gate.gate_f.requires_grad or tb.attn2.gate.gate_f.requires_grad \
+            or tb.ff.net[0].gate.gate_f.requires_grad
+        if self.depth_gated:
+            req = req or self.depth_gate.gate_f.requires_grad
+        return bool(req)
+
+    def _forward_train(self, x, encoder_hidden_states):
+        from . import autograd as AG
+        dev = x.device
+        pl = self.plan(dev, force_dense=True)
+        tb = self.transformer_blocks[0]
+        B, H, W, C = x.shape
+        P = H * W
+
+        def bwd(name, make_w):
+            def get():
+                key = name + "_bwd"
+                if key not in pl:
+                    pl[key] = ops.pack_weight_dgrad(make_w().detach(), device=dev)
+                return pl[key]
+            return get
+
+        def gated(y0, gate, rep=1):
+            g = gate.gate_f
+            hu = gate.hard_uniform()
+            if not g.requires_grad and hu is not None and bool((hu == 1).all()):
+                return y0
+            g = g.to(device=dev, dtype=torch.float32)
+            return AG.GateFn.apply(y0, g.repeat(1, rep) if rep > 1 else g)
+
+        a = AG.GroupNormFn.apply(x, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False)
+        tok = a.reshape(B, P, C)
+        x_tok = x.reshape(B, P, C)
+        h = AG.conv(tok, pl["proj_in"], bwd("proj_in", lambda: self.proj_in.weight), pad=0)
+        # self attention
+        n = AG.LayerNormFn.apply(h, pl["ln1_g"], pl["ln1_b"], 1e-5)
+        a1 = tb.attn1
+        qkv = AG.conv(n, pl["a1_qkv"], bwd("a1_qkv", lambda: torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)), pad=0)
+        qkv = gated(qkv, a1.gate, 3)
+        o = AG.SelfAttnFn.apply(qkv, a1.heads)
+        h = AG.conv(o, pl["a1_o"], bwd("a1_o", lambda: a1.to_out[0].weight), pad=0) + h
+        # cross attention
+        n = AG.LayerNormFn.apply(h, pl["ln2_g"], pl["ln2_b"], 1e-5)
+        a2 = tb.attn2
+        q = gated(AG.conv(n, pl["a2_q"], bwd("a2_q", lambda: a2.to_q.weight), pad=0), a2.gate)
+        ehs = encoder_hidden_states.ehs if isinstance(encoder_hidden_states, CtxBundle) else \
+            encoder_hidden_states.to(device=dev, dtype=torch.bfloat16)
+        if "a2_kv" not in pl:
+            pl["a2_kv"] = ops.pack_weight(pl["a2_kv_w"], None, device=dev)
+        kv = gated(AG.conv(ehs, pl["a2_kv"], None, pad=0), a2.gate, 2)
+        o = AG.CrossAttnFn.apply(q, kv, a2.heads)
+        h = AG.conv(o, pl["a2_o"], bwd("a2_o", lambda: a2.to_out[0].weight), pad=0) + h
+        # feed-forward (GEGLU in its un-interleaved training form)
+        n = AG.LayerNormFn.apply(h, pl["ln3_g"], pl["ln3_b"], 1e-5)
+        geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
+        if "ff1_plain" not in pl:
+            pl["ff1_plain"] = ops.pack_weight(geglu.proj.weight.detach(), geglu.proj.bias.detach(), device=dev)
+        hg = AG.conv(n, pl["ff1_plain"], bwd("ff1_plain", lambda: geglu.proj.weight), pad=0)
+        fg = geglu.gate.gate_f
+        hu = geglu.gate.hard_uniform()
+        ffgate = None if (not fg.requires_grad and hu is not None and bool((hu == 1).all())) else fg.to(device=dev, dtype=torch.float32)
+        f = AG.GegluFn.apply(hg, ffgate)
+        h = AG.conv(f, pl["ff2"], bwd("ff2", lambda: lin2.weight), pad=0) + h
+        out = AG.conv(h, pl["proj_out"], bwd("proj_out", lambda: self.proj_out.weight), pad=0) + x_tok
+        if self.depth_gated:
+            d = self.depth_gate.gate_f
+            d_hard, _ = self._depth_state()
+            if d.requires_grad or d_hard != 1.0:
+                out = AG.depth_lerp(x_tok, out, d.to(device=dev, dtype=torch.float32))
+        return _nchw(out.reshape(B, H, W, C))
+
     # ---- forward --------------------------------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None,
                 class_labels=None, cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None,
@@ -463,6 +585,8 @@ class Transformer2DModelWidthGated(nn.Module):
         if attention_mask is not None or encoder_attention_mask is not None:
             raise NotImplementedError("attention masks are not used on the APTP path (pruning_pipelines.py:796-802)")
         x = _nhwc(hidden_states)
+        if self._needs_autograd(x) and not (self.depth_gated and self.dropped):
+            return self._ret(self._forward_train(x, encoder_hidden_states), return_dict)
         d_hard, d_vec = self._depth_state()
         if self.depth_gated and (self.dropped or d_hard == 0.0):
             return self._ret(hidden_states, return_dict)                  # blocks.py:1190-1194
@@ -575,7 +699,18 @@ class Downsample2D(nn.Module):
         x = _nhwc(hidden_states)
         if self._pw is None or self._pw.w.device != x.device:
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
+            self._pwb = None
+        if torch.is_grad_enabled() and x.requires_grad:
+            from . import autograd as AG
+            return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), stride=2, pad=1))
         return _nchw(ops.conv_gemm(x, self._pw, stride=2, pad=1))
+
+    def _get_bwd(self, dev):
+        def get():
+            if getattr(self, "_pwb", None) is None:
+                self._pwb = ops.pack_weight_dgrad(self.conv.weight.detach(), device=dev)
+            return self._pwb
+        return get
 
 
 class Upsample2D(nn.Module):
@@ -593,7 +728,18 @@ class Upsample2D(nn.Module):
         x = _nhwc(hidden_states)
         if self._pw is None or self._pw.w.device != x.device:
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
+            self._pwb = None
+        if torch.is_grad_enabled() and x.requires_grad:
+            from . import autograd as AG
+            return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), ups=1))
         return _nchw(ops.conv_gemm(x, self._pw, ups=1))
+
+    def _get_bwd(self, dev):
+        def get():
+            if getattr(self, "_pwb", None) is None:
+                self._pwb = ops.pack_weight_dgrad(self.conv.weight.detach(), device=dev)
+            return self._pwb
+        return get
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -754,6 +900,8 @@ class UpBlock2DWidthHalfDepthGated(CrossAttnUpBlock2DWidthHalfDepthGated):
 def _cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], dim=1) for channels_last activations, produced directly in NHWC memory."""
     A, Bn = _nhwc(a), _nhwc(b)
+    if torch.is_grad_enabled() and (A.requires_grad or Bn.requires_grad):
+        return _nchw(torch.cat([A, Bn], dim=3))
     out = torch.empty(A.shape[0], A.shape[1], A.shape[2], A.shape[3] + Bn.shape[3], dtype=A.dtype, device=A.device)
     out[..., :A.shape[3]].copy_(A)
     out[..., A.shape[3]:].copy_(Bn)
@@ -1126,8 +1274,18 @@ class UNet2DConditionModelGated(nn.Module):
             down_block_res_samples = down_block_res_samples[:-n_res]
             h = blk(hidden_states=h, temb=temb, res_hidden_states_tuple=res, encoder_hidden_states=ctx)
         # 6. post-process
-        a = ops.groupnorm(_nhwc(h), misc["gn_g"], misc["gn_b"], self.conv_norm_out.num_groups, self.conv_norm_out.eps, True)
-        y = ops.conv_gemm(a, misc["conv_out"], out_f32=True)                # fp32 [B,H,W,roundup8(out)]
+        if torch.is_grad_enabled() and h.requires_grad:
+            from . import autograd as AG
+
+            def get_out_bwd():
+                if "conv_out_bwd" not in misc:
+                    misc["conv_out_bwd"] = ops.pack_weight_dgrad(self.conv_out.weight.detach(), device=dev)
+                return misc["conv_out_bwd"]
+            a = AG.GroupNormFn.apply(_nhwc(h), misc["gn_g"], misc["gn_b"], self.conv_norm_out.num_groups, self.conv_norm_out.eps, True)
+            y = AG.conv(a, misc["conv_out"], get_out_bwd, out_f32=True)
+        else:
+            a = ops.groupnorm(_nhwc(h), misc["gn_g"], misc["gn_b"], self.conv_norm_out.num_groups, self.conv_norm_out.eps, True)
+            y = ops.conv_gemm(a, misc["conv_out"], out_f32=True)            # fp32 [B,H,W,roundup8(out)]
         out = y[..., :self.out_channels].permute(0, 3, 1, 2).to(out_dtype)
         if not return_dict:
             return (out,)

@@ -1,0 +1,215 @@
+"""The pruning train step of APTP on synthetic batches (e): the counterpart of ``Pruner.step``
+(pdm/training/trainer.py:1092-1254) plus the data-parallel gradient exchange that accelerate/DDP performs there
+(:922).
+
+What is reproduced: router (:1129-1138), cross-rank gather of text embeddings / normalised arch vectors with the local
+slot re-inserted to keep autograd (:1147-1162), teacher forward with the all-ones structure under ``no_grad``
+(:1185-1190), student forward with per-sample soft gates (:1192-1195), min-SNR weighted MSE with ``snr + 1`` for
+v-prediction (:1197-1216), distillation + block-distillation on the 9 hooked block outputs (:496-511, 1218-1225),
+resource / std / max losses from ``calc_macs`` (:1227-1238), and the loss weights of configs/pruning/sd-2-1_cc3m.yaml
+(:86-111).  What is not: VAE / CLIP / MPNet encoders, datasets, logging, checkpointing (not on the U-Net path; the
+batch arrives as latents, text states, MPNet embeddings and a target).
+
+MI355X-first: one process per GPU; the trainable state is 1.26 M router parameters, so the per-step gradient
+exchange is ONE flat fp32 all-reduce (~5 MB, latency-bound) over RCCL instead of DDP's bucket machinery, and the two
+small all-gathers of the step are fused into one.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .losses import ContrastiveLoss, ResourceLoss, compute_snr
+
+
+@dataclass
+class PruningLossConfig:
+    """configs/pruning/sd-2-1_cc3m.yaml:86-111"""
+    snr_gamma: Optional[float] = 5.0
+    prediction_type: str = "v_prediction"
+    resource_weight: float = 2.0
+    resource_type: str = "log"
+    pruning_target: float = 0.6
+    contrastive_weight: float = 100.0
+    arch_vector_temperature: float = 0.03
+    prompt_embedding_temperature: float = 0.03
+    distillation_weight: float = 0.2
+    block_weight: float = 0.2
+    std_weight: float = 0.1
+    max_weight: float = 0.1
+
+
+class NoiseSchedule:
+    """scaled-linear DDPM betas of SD-2.1 (only ``alphas_cumprod`` is needed by compute_snr)"""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+
+
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def gather_with_local_grad(*tensors: torch.Tensor) -> List[torch.Tensor]:
+    """trainer.py:1147-1162: all-gather [B_loc, d_i] tensors across ranks under no_grad, re-insert the local block so
+    gradients flow to the local rows only.  The tensors are concatenated along dim 1 so the step issues ONE collective."""
+    world, rank = _world(), _rank()
+    if world == 1:
+        return list(tensors)
+    widths = [t.shape[1] for t in tensors]
+    with torch.no_grad():
+        flat = torch.cat([t.detach().float() for t in tensors], dim=1).contiguous()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+    outs = []
+    off = 0
+    for t, w in zip(tensors, widths):
+        blocks = [g[:, off:off + w].to(t.dtype) for g in gathered]
+        blocks[rank] = t
+        outs.append(torch.cat(blocks, dim=0))
+        off += w
+    return outs
+
+
+def allreduce_mean_grads(params) -> None:
+    """One flat all-reduce (mean) of all router gradients: the DDP exchange of Pruner."""
+    world = _world()
+    if world == 1:
+        return
+    params = [p for p in params if p.requires_grad]
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    dist.all_reduce(flat)
+    flat /= world
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[off:off + n].view_as(p).to(p.dtype)
+        off += n
+
+
+class PrunerStep:
+    def __init__(self, unet, hyper_net, quantizer, cfg: Optional[PruningLossConfig] = None,
+                 schedule: Optional[NoiseSchedule] = None):
+        self.unet, self.hyper_net, self.quantizer = unet, hyper_net, quantizer
+        self.cfg = cfg or PruningLossConfig()
+        self.schedule = schedule or NoiseSchedule()
+        self.contrastive = ContrastiveLoss(self.cfg.arch_vector_temperature, self.cfg.prompt_embedding_temperature)
+        self.resource = ResourceLoss(p=self.cfg.pruning_target, loss_type=self.cfg.resource_type)
+        self.block_activations: Dict[str, torch.Tensor] = {}
+        self._hooks = []
+        self._cast_block_act_hooks()
+
+    # trainer.py:496-511
+    def _cast_block_act_hooks(self):
+        acts = self.block_activations
+
+        def mk(name, residuals_present):
+            if residuals_present:
+                return lambda m, i, o: acts.__setitem__(name, o[0])
+            return lambda m, i, o: acts.__setitem__(name, o)
+        for i, b in enumerate(self.unet.down_blocks):
+            self._hooks.append(b.register_forward_hook(mk("d" + str(i), True)))
+        self._hooks.append(self.unet.mid_block.register_forward_hook(mk("m", False)))
+        for i, b in enumerate(self.unet.up_blocks):
+            self._hooks.append(b.register_forward_hook(mk("u" + str(i), False)))
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    @torch.no_grad()
+    def count_macs(self, latent_size: int):
+        """trainer.py:1256-1306: MAC constants with the all-ones structure, prunable-MAC template, actual target p."""
+        ones = self.hyper_net.transform_structure_vector(
+            torch.ones((1, self.quantizer.vq_embed_dim), device=next(self.hyper_net.parameters()).device))
+        self.unet.set_structure(ones)
+        self.unet.count_macs(latent_size)
+        self.quantizer.set_prunable_macs_template([list(x) for x in self.unet.prunable_macs_list])
+        info = self.unet.resource_info_dict
+        p = self.cfg.pruning_target
+        self.resource.p = float(1 - (1 - p) * info["total_macs"] / float(torch.as_tensor(info["cur_prunable_macs"]).flatten()[0]))
+
+    def step(self, noisy_latents, timesteps, encoder_hidden_states, text_embeddings, target, pretrain: bool = False):
+        cfg = self.cfg
+        arch_vector = self.hyper_net(text_embeddings)                                           # :1129
+        arch_vector_quantized, _ = self.quantizer(arch_vector)                                  # :1130
+        arch_vector = self.quantizer.gumbel_sigmoid_trick(arch_vector)                          # :1132
+        arch_wdn = self.quantizer.width_depth_normalize(arch_vector)                            # :1138
+        text_all, arch_all = gather_with_local_grad(text_embeddings, arch_wdn)                  # :1147-1162 (one collective)
+        sep = self.hyper_net.transform_structure_vector(arch_vector if pretrain else arch_vector_quantized)   # :1165-1168
+        contrastive_loss = self.contrastive(text_all, arch_all)                                 # :1170-1171
+
+        with torch.no_grad():                                                                   # :1185-1190 teacher
+            full = self.hyper_net.transform_structure_vector(torch.ones_like(arch_vector))
+            self.unet.set_structure(full)
+            full_pred = self.unet(noisy_latents, timesteps, encoder_hidden_states).sample.detach()
+            teacher_acts = dict(self.block_activations)
+        self.unet.set_structure(sep)                                                            # :1192-1195 student
+        model_pred = self.unet(noisy_latents, timesteps, encoder_hidden_states).sample
+        student_acts = dict(self.block_activations)
+
+        if cfg.snr_gamma is None:                                                               # :1197-1216
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+        else:
+            snr = compute_snr(self.schedule, timesteps)
+            if cfg.prediction_type == "v_prediction":
+                snr = snr + 1
+            w = torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
+            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
+        distillation_loss = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")  # :1218
+        block_loss = torch.zeros((), device=model_pred.device)
+        for k in student_acts:                                                                  # :1220-1225
+            block_loss = block_loss + F.mse_loss(student_acts[k].float(), teacher_acts[k].detach().float(), reduction="mean")
+        block_loss = block_loss / len(student_acts)
+
+        macs = self.unet.calc_macs()                                                            # :1227-1238
+        ratios = macs["cur_prunable_macs"] / self.unet.resource_info_dict["cur_prunable_macs"].squeeze()
+        resource_loss = self.resource(ratios.mean())
+        max_loss = 1.0 - torch.max(ratios)
+        std_loss = -torch.std(ratios)
+
+        diff_loss = loss.detach().clone()
+        loss = loss + cfg.resource_weight * resource_loss + cfg.contrastive_weight * contrastive_loss \
+            + cfg.distillation_weight * distillation_loss + cfg.block_weight * block_loss \
+            + cfg.std_weight * std_loss + cfg.max_weight * max_loss                               # :1240-1249
+        return {"loss": loss, "diff_loss": diff_loss, "distillation_loss": distillation_loss.detach(),
+                "block_loss": block_loss.detach(), "contrastive_loss": contrastive_loss.detach(),
+                "resource_loss": resource_loss.detach(), "resource_ratio": ratios.mean().detach(),
+                "arch_vector_quantized": arch_vector_quantized.detach()}
+
+    def trainable_parameters(self):
+        return [p for p in list(self.hyper_net.parameters()) + list(self.quantizer.parameters()) if p.requires_grad]
+
+    def train_step(self, optimizer, batch: dict, pretrain: bool = False):
+        """forward + backward + fused gradient all-reduce + optimizer step (trainer.py:913-933)"""
+        optimizer.zero_grad(set_to_none=True)
+        out = self.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"],
+                        batch["mpnet_embeddings"], batch["target"], pretrain=pretrain)
+        out["loss"].backward()
+        allreduce_mean_grads(self.trainable_parameters())
+        optimizer.step()
+        return out
+
+
+def synthetic_batch(batch: int, latent: int, device, seed: int = 1234, cross_dim: int = 1024, text_dim: int = 768):
+    """SURVEY §8d synthetic CC3M-shape batch: latents/target N(0,1), text states N(0,1), MPNet embeddings 0.05*N(0,1),
+    random integer timesteps."""
+    g = torch.Generator().manual_seed(seed)
+    return {
+        "noisy_latents": torch.randn(batch, 4, latent, latent, generator=g).to(device),
+        "target": torch.randn(batch, 4, latent, latent, generator=g).to(device),
+        "encoder_hidden_states": torch.randn(batch, 77, cross_dim, generator=g).to(device),
+        "mpnet_embeddings": (0.05 * torch.randn(batch, text_dim, generator=g)).to(device),
+        "timesteps": torch.randint(0, 1000, (batch,), generator=g).to(device),
+    }

@@ -1,0 +1,142 @@
+"""GPU end-to-end parity of the pruning train step: PrunerStep on the HIP path vs the SAME step logic
+driven by the fp32 CPU oracle U-Net (identical router weights, identical host-RNG gumbel noise, identical batch)."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEPTH_ORDER = [-1, -2, 0, 1, -3, -4, 2, 3, -5, -6, 4, 5, -7, 6]
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+class _Pass(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class OracleUNetAdapter:
+    """Reference-API facade over the oracle: set_structure / __call__ / calc_macs / hookable blocks."""
+
+    def __init__(self, params, cfg, macs_model):
+        self.params, self.cfg, self.macs_model = params, cfg, macs_model
+        self.down_blocks = nn.ModuleList([_Pass() for _ in range(4)])
+        self.mid_block = _Pass()
+        self.up_blocks = nn.ModuleList([_Pass() for _ in range(4)])
+        self.gates = {}
+
+    def set_structure(self, sep):
+        w, d = list(sep["width"]), list(sep["depth"])
+        self.gates = O.assign_gates(self.cfg, {"width": list(w), "depth": list(d)})
+        self.macs_model.set_structure({"width": list(w), "depth": list(d)})
+
+    def __call__(self, sample, t, ehs):
+        out, blocks = O.unet_forward(self.params, self.cfg, sample, t, ehs, self.gates, "gated", return_blocks=True)
+        for i in range(4):
+            self.down_blocks[i]((blocks[i], None))
+        self.mid_block(blocks[4])
+        for i in range(4):
+            self.up_blocks[i](blocks[5 + i])
+
+        class R:
+            pass
+        r = R()
+        r.sample = out
+        return r
+
+    def calc_macs(self):
+        return self.macs_model.calc_macs()
+
+    def count_macs(self, n):
+        return self.macs_model.count_macs(n)
+
+    @property
+    def prunable_macs_list(self):
+        return self.macs_model.prunable_macs_list
+
+    @property
+    def resource_info_dict(self):
+        return self.macs_model.resource_info_dict
+
+
+def build(cuda):
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    cfg = O.TINY
+    kw = dict(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads, cross_attention_dim=cfg.cross_attention_dim)
+    unet = UNet2DConditionModelGated(**kw).init_synthetic(seed=0)
+    params = {k: v.detach().clone() for k, v in unet.state_dict().items()}
+    macs_model = UNet2DConditionModelGated(**kw)           # CPU instance: only its (pure-torch) MAC accounting is used
+    structure = unet.get_structure()
+    torch.manual_seed(11)
+    hn = HyperStructure(structure=structure, input_dim=32, wn_flag=False, linear_bias=True)
+    qz = StructureVectorQuantizer(n_e=4, structure=structure, temperature=0.4, base=3, depth_order=DEPTH_ORDER,
+                                  resource_aware_normalization=False, optimal_transport=True)
+    return cfg, unet, params, macs_model, hn, qz
+
+
+def test_pruning_step_matches_oracle_driven_step(cuda):
+    from diffusion_pruning_amd.train_step import PrunerStep, PruningLossConfig, synthetic_batch
+    cfg, unet, params, macs_model, hn, qz = build(cuda)
+    hn_ref, qz_ref = copy.deepcopy(hn), copy.deepcopy(qz)
+    unet.to(cuda).freeze()
+    hn.to(cuda); qz.to(cuda)
+    lcfg = PruningLossConfig()
+    batch_cpu = synthetic_batch(4, 16, "cpu", seed=7, cross_dim=cfg.cross_attention_dim, text_dim=32)
+    batch_gpu = {k: v.to(cuda) for k, v in batch_cpu.items()}
+
+    step = PrunerStep(unet, hn, qz, lcfg)
+    hn.train(); qz.train()
+    step.count_macs(16)
+    torch.manual_seed(123)
+    out = step.step(batch_gpu["noisy_latents"], batch_gpu["timesteps"], batch_gpu["encoder_hidden_states"],
+                    batch_gpu["mpnet_embeddings"], batch_gpu["target"], pretrain=True)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+
+    ref_unet = OracleUNetAdapter(params, cfg, macs_model)
+    ref = PrunerStep(ref_unet, hn_ref, qz_ref, lcfg)
+    hn_ref.train(); qz_ref.train()
+    ref.count_macs(16)
+    torch.manual_seed(123)
+    out_ref = ref.step(batch_cpu["noisy_latents"], batch_cpu["timesteps"], batch_cpu["encoder_hidden_states"],
+                       batch_cpu["mpnet_embeddings"], batch_cpu["target"], pretrain=True)
+    out_ref["loss"].backward()
+
+    for k in ("diff_loss", "distillation_loss", "block_loss", "contrastive_loss", "resource_loss", "resource_ratio"):
+        a, b = float(out[k]), float(out_ref[k])
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (k, a, b)
+    assert abs(float(out["loss"]) - float(out_ref["loss"])) <= 2e-2 * abs(float(out_ref["loss"]))
+    # gradients reaching the hyper-net through the U-Net (pretrain=True feeds the un-quantised vector to the U-Net)
+    g = torch.cat([p.grad.float().cpu().flatten() for p in hn.parameters()])
+    g_ref = torch.cat([p.grad.flatten() for p in hn_ref.parameters()])
+    assert torch.isfinite(g).all() and float(g_ref.abs().sum()) > 0
+    assert rel_l2(g, g_ref) <= 8e-2, rel_l2(g, g_ref)
+
+
+def test_two_optimizer_steps_change_the_router(cuda):
+    from diffusion_pruning_amd.train_step import PrunerStep, synthetic_batch
+    cfg, unet, params, macs_model, hn, qz = build(cuda)
+    unet.to(cuda).freeze()
+    hn.to(cuda); qz.to(cuda)
+    step = PrunerStep(unet, hn, qz)
+    hn.train(); qz.train()
+    step.count_macs(16)
+    opt = torch.optim.AdamW(step.trainable_parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in step.trainable_parameters()]
+    batch = synthetic_batch(4, 16, cuda, seed=3, cross_dim=cfg.cross_attention_dim, text_dim=32)
+    losses = []
+    for i in range(2):
+        out = step.train_step(opt, batch, pretrain=(i == 0))
+        assert torch.isfinite(out["loss"])
+        losses.append(float(out["loss"]))
+    moved = sum(float((a - b.detach()).abs().sum()) for a, b in zip(before, step.trainable_parameters()))
+    assert moved > 0
+    assert qz.embedding.weight.grad is not None        # step 2 (pretrain=False) routes through the codebook

@@ -34,18 +34,19 @@ struct RowK {
   int B, HW, C, CO, G, cg, nchunk, TPR, RPAR;
 };
 
-__device__ __forceinline__ void fold_channels_to_groups(const RowK& k, float (*red)[4096], int nacc, int CP, int tid,
+__device__ __forceinline__ void fold_channels_to_groups(const RowK& k, float (*red)[6144], int nacc, int CP, int tid,
                                                         float* out /* [G][nacc] */) {
-  // 8 threads per group fold channels x RPAR for `nacc` accumulators held in red[a][rl*CP + c]
-  const int g = tid >> 3, sub = tid & 7;
+  // TPG (8/4/2 for G <= 32/64/128) threads per group fold channels x RPAR for `nacc` accumulators held in
+  // red[a][rl*CP + c]; fixed order => deterministic
+  const int tpg = k.G <= 32 ? 8 : (k.G <= 64 ? 4 : 2);
+  const int g = tid / tpg, sub = tid % tpg;
   for (int a = 0; a < nacc; ++a) {
     float v = 0.f;
     if (g < k.G) {
       for (int rr = 0; rr < k.RPAR; ++rr)
-        for (int i = sub; i < k.cg; i += 8) v += red[a][rr * CP + g * k.cg + i];
+        for (int i = sub; i < k.cg; i += tpg) v += red[a][rr * CP + g * k.cg + i];
     }
-#pragma unroll
-    for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    for (int off = tpg >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     if (g < k.G && sub == 0) out[g * nacc + a] = v;
   }
 }
@@ -61,7 +62,7 @@ struct GateBwdK {
 
 template <int NP>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwdK p) {
-  __shared__ float red[1][4096];
+  __shared__ float red[1][6144];
   const RowK& k = p.r;
   const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
   const int r0 = (int)(((int64_t)k.HW * chunk) / k.nchunk), r1 = (int)(((int64_t)k.HW * (chunk + 1)) / k.nchunk);
@@ -124,7 +125,7 @@ struct GegluK {
 
 template <int NP, bool BWD>
 __global__ __launch_bounds__(256) void geglu_kernel(const GegluK p) {
-  __shared__ float red[1][4096];
+  __shared__ float red[1][6144];
   const RowK& k = p.r;
   const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
   const int r0 = (int)(((int64_t)k.HW * chunk) / k.nchunk), r1 = (int)(((int64_t)k.HW * (chunk + 1)) / k.nchunk);
@@ -235,7 +236,7 @@ __device__ __forceinline__ void fold_forward_stats(const GnBwdK& p, int b, int t
 
 template <int NP, bool APPLY>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdK p) {
-  __shared__ float red[2][4096];
+  __shared__ float red[2][6144];
   __shared__ float mean_s[32], rstd_s[32], s1_s[32], s2_s[32];
   const RowK& k = p.r;
   const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
@@ -405,9 +406,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdK p) {
 }
 
 int fill_rowk(RowK& k, int B, int HW, int C, int G, const char* what) {
-  APTP_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 32 && C % G == 0, "%s: bad extents (B=%d HW=%d C=%d G=%d)", what, B, HW, C, G);
+  APTP_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 128 && C % G == 0, "%s: bad extents (B=%d HW=%d C=%d G=%d)", what, B, HW, C, G);
   k.B = B; k.HW = HW; k.C = C; k.G = G; k.cg = C / G; k.CO = (C + 7) / 8;
-  APTP_CHECK(k.CO <= 512, "%s: C too large", what);
+  APTP_CHECK(k.CO <= 768, "%s: C too large (max 6144)", what);
   k.nchunk = aptp_groupnorm_nchunk(HW);
   k.TPR = k.CO < 256 ? k.CO : 256;
   k.RPAR = 256 / k.TPR;
@@ -429,7 +430,8 @@ extern "C" int aptp_gate_bwd(const AptpGateBwdParams* p, aptp_stream_t stream) {
   k.dx = (__bf16*)p->dx; k.lddx = p->lddx; k.gate = p->gate; k.gate_B = p->gate_B; k.partial = p->dgate_partial;
   dim3 grid(k.r.nchunk, p->B);
   if (k.r.CO <= 256) hipLaunchKernelGGL(gate_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL(gate_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
+  else if (k.r.CO <= 512) hipLaunchKernelGGL(gate_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(gate_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, k);
   APTP_LAUNCH_CHECK();
   return APTP_OK;
 }
@@ -450,12 +452,14 @@ extern "C" int aptp_geglu(const AptpGegluParams* p, aptp_stream_t stream) {
   if (!p->backward) {
     APTP_CHECK(p->out && p->ldout % 8 == 0 && p->ldout >= p->C && ALIGN16(p->out), "geglu: out");
     if (k.r.CO <= 256) hipLaunchKernelGGL((geglu_kernel<1, false>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((geglu_kernel<2, false>), grid, dim3(256), 0, s, k);
+    else if (k.r.CO <= 512) hipLaunchKernelGGL((geglu_kernel<2, false>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((geglu_kernel<3, false>), grid, dim3(256), 0, s, k);
   } else {
     APTP_CHECK(p->dout && p->dhg && p->dgate_partial && p->lddout % 8 == 0 && p->lddhg % 8 == 0 && p->lddhg >= 2 * p->C
                && ALIGN16(p->dout) && ALIGN16(p->dhg), "geglu: backward operands");
     if (k.r.CO <= 256) hipLaunchKernelGGL((geglu_kernel<1, true>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((geglu_kernel<2, true>), grid, dim3(256), 0, s, k);
+    else if (k.r.CO <= 512) hipLaunchKernelGGL((geglu_kernel<2, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((geglu_kernel<3, true>), grid, dim3(256), 0, s, k);
   }
   APTP_LAUNCH_CHECK();
   return APTP_OK;
@@ -466,6 +470,7 @@ extern "C" int aptp_groupnorm_bwd(const AptpGroupNormBwdParams* p, aptp_stream_t
   GnBwdK k;
   const int rc = fill_rowk(k.r, p->B, p->HW, p->C, p->groups, "groupnorm_bwd");
   if (rc) return rc;
+  APTP_CHECK(p->groups <= 32 && k.r.CO <= 512, "groupnorm_bwd: groups <= 32, C <= 4096");
   APTP_CHECK(p->ldx % 8 == 0 && p->lddy % 8 == 0 && p->lddx % 8 == 0 && ALIGN16(p->x) && ALIGN16(p->dy) && ALIGN16(p->dx), "groupnorm_bwd: alignment");
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dx = (__bf16*)p->dx; k.lddx = p->lddx;
   k.gamma = p->gamma; k.beta = p->beta; k.eps = p->eps; k.silu = p->silu;

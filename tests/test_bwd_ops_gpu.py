@@ -99,12 +99,20 @@ def test_gate_bwd_and_apply(ops, cuda):
     # the same kernel doubles as the forward gate multiply (dy := y0)
     fwd, _ = ops.gate_bwd(y0.bfloat16().to(cuda), y0.bfloat16().to(cuda), gate.detach().to(cuda))
     assert rel_l2(fwd.float().cpu(), y1.detach()) <= 4e-3
+    # 60 gate entries (fused QKV of a 20-head layer): 4 threads per group
+    y0 = torch.randn(2, 4, 4, 3840, generator=g).bfloat16().float()
+    gate = torch.rand(2, 60, generator=g).requires_grad_()
+    mask = gate.repeat_interleave(64, dim=1)[:, None, None, :]
+    dy = torch.randn(y0.shape, generator=g).bfloat16().float()
+    (y0 * mask).backward(dy)
+    dx, dgate = ops.gate_bwd(dy.bfloat16().to(cuda), y0.bfloat16().to(cuda), gate.detach().to(cuda))
+    assert rel_l2(dx.float().cpu(), dy * mask.detach()) <= 4e-3 and rel_l2(dgate.cpu(), gate.grad) <= 2e-3
 
 
-@pytest.mark.parametrize("use_gate", [True, False])
-def test_geglu_fwd_bwd(ops, cuda, use_gate):
+@pytest.mark.parametrize("use_gate,C", [(True, 256), (False, 256), (True, 5120)])
+def test_geglu_fwd_bwd(ops, cuda, use_gate, C):
     g = torch.Generator().manual_seed(5)
-    B, L, C = 2, 40, 256
+    B, L = 2, 40
     hg = torch.randn(B, L, 2 * C, generator=g).bfloat16().float().requires_grad_()
     gate = torch.rand(2, 32, generator=g).requires_grad_() if use_gate else None
     h, gg = hg.chunk(2, dim=-1)

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libaptp_hip.so")
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x160, TILE_64x128, TILE_64x160, TILE_128x64, TILE_64x64 = range(7)
 (TILE_DMA_128x128, TILE_DMA_128x160, TILE_DMA_64x128, TILE_DMA_64x160, TILE_DMA_128x64, TILE_DMA_64x64) = range(7, 13)
+(TILE_DMA3_128x128, TILE_DMA3_128x160, TILE_DMA3_64x128, TILE_DMA3_64x160, TILE_DMA3_128x64, TILE_DMA3_64x64) = range(13, 19)
 
 
 class ConvGemmParams(Structure):

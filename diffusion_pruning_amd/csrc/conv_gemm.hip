@@ -318,16 +318,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 __device__ uint4 g_zero16[2];
 
-template <int BM, int BN, int WM, int WN>
+// STAGES = 2: double buffer, one __syncthreads() per K-step (the LDS-DMA of step t+1 overlaps the MFMAs of step t).
+// STAGES = 3: ring of three buffers, the DMA runs TWO K-steps ahead; a counted s_waitcnt vmcnt(N) (N = the DMA
+//             instructions this thread issued for the newest tile) retires only the older tile, and a raw s_barrier
+//             (no implicit vmcnt(0)) publishes it, so one tile stays in flight across every barrier.
+template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MF = WTM / 16, NF = WTN / 16;
   constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
 
-  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[STAGES * (BM + BN) * BK];
   __bf16* As = smem;
-  __bf16* Bs = smem + 2 * BM * BK;
+  __bf16* Bs = smem + STAGES * BM * BK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -430,15 +434,44 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
     }
   };
 
-  if (kt_begin < kt_end) {
-    issue_tile(0);
-    __syncthreads();                       // (the compiler drains vmcnt(0) for the LDS-DMA before the barrier)
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      if (kt + 1 < kt_end) issue_tile(buf ^ 1);   // in flight during the MFMAs below
-      compute(buf);
-      __syncthreads();
-      buf ^= 1;
+  if constexpr (STAGES == 2) {
+    if (kt_begin < kt_end) {
+      issue_tile(0);
+      __syncthreads();                       // (the compiler drains vmcnt(0) for the LDS-DMA before the barrier)
+      int buf = 0;
+      for (int kt = kt_begin; kt < kt_end; ++kt) {
+        if (kt + 1 < kt_end) issue_tile(buf ^ 1);   // in flight during the MFMAs below
+        compute(buf);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+  } else {
+    constexpr int NLD = A_PASS + B_PASS;     // LDS-DMA instructions per thread per tile
+    if (kt_begin < kt_end) {
+      issue_tile(0);
+      if (kt_begin + 1 < kt_end) {
+        issue_tile(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // tile 0 landed, tile 1 still in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int cur = 0;
+      for (int kt = kt_begin; kt < kt_end; ++kt) {
+        int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
+        const bool issue = kt + 2 < kt_end;
+        if (issue) issue_tile(nxt2);           // stage (kt+2)%3 == (kt-1)%3: last read before the previous barrier
+        compute(cur);
+        asm volatile("" ::: "memory");
+        if (issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // tile kt+1 landed; kt+2 in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // this wave's LDS reads of `cur` are done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur = cur + 1 == 3 ? 0 : cur + 1;
+      }
     }
   }
 
@@ -515,7 +548,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
 
 struct TileCfg { int bm, bn; };
 const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},
-                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64}};   // 7..12: LDS-DMA variants
+                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},    // 7..12: LDS-DMA, 2 stages
+                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64}};   // 13..18: LDS-DMA, 3 stages
+constexpr int kNumTiles = 19;
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
   if (p->tile != APTP_TILE_AUTO) return p->tile;
@@ -588,11 +623,11 @@ void launch_tile(const KParams& k, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int STAGES>
 void launch_tile_dma(const KParams& k, hipStream_t s) {
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
   dim3 grid(tiles, k.split_k, 1);
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, 2, STAGES>), grid, dim3(256), 0, s, k);
 }
 
 }  // namespace
@@ -623,8 +658,8 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   if (k.split_k > 1) APTP_CHECK(k.ws != nullptr && ((uintptr_t)k.ws % 16) == 0, "conv_gemm: split_k > 1 needs a 16B-aligned workspace");
   hipStream_t s = (hipStream_t)stream;
   int t = pick_tile(p, k.M);
-  if (t < 0 || t > 12) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
-  if (k.act == APTP_ACT_GEGLU && (kTiles[t < 13 ? t : 0].bn == 160)) {
+  if (t < 0 || t >= kNumTiles) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
+  if (k.act == APTP_ACT_GEGLU && (kTiles[t].bn == 160)) {
     aptp_set_error("conv_gemm: GEGLU cannot use a 160-wide tile");
     return APTP_EINVAL;
   }
@@ -635,12 +670,18 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_64x160: launch_tile<64, 160>(k, s); break;
     case APTP_TILE_128x64: launch_tile<128, 64>(k, s); break;
     case APTP_TILE_64x64: launch_tile<64, 64>(k, s); break;
-    case APTP_TILE_DMA_128x128: launch_tile_dma<128, 128>(k, s); break;
-    case APTP_TILE_DMA_128x160: launch_tile_dma<128, 160>(k, s); break;
-    case APTP_TILE_DMA_64x128: launch_tile_dma<64, 128>(k, s); break;
-    case APTP_TILE_DMA_64x160: launch_tile_dma<64, 160>(k, s); break;
-    case APTP_TILE_DMA_128x64: launch_tile_dma<128, 64>(k, s); break;
-    case APTP_TILE_DMA_64x64: launch_tile_dma<64, 64>(k, s); break;
+    case APTP_TILE_DMA_128x128: launch_tile_dma<128, 128, 2>(k, s); break;
+    case APTP_TILE_DMA_128x160: launch_tile_dma<128, 160, 2>(k, s); break;
+    case APTP_TILE_DMA_64x128: launch_tile_dma<64, 128, 2>(k, s); break;
+    case APTP_TILE_DMA_64x160: launch_tile_dma<64, 160, 2>(k, s); break;
+    case APTP_TILE_DMA_128x64: launch_tile_dma<128, 64, 2>(k, s); break;
+    case APTP_TILE_DMA_64x64: launch_tile_dma<64, 64, 2>(k, s); break;
+    case APTP_TILE_DMA3_128x128: launch_tile_dma<128, 128, 3>(k, s); break;
+    case APTP_TILE_DMA3_128x160: launch_tile_dma<128, 160, 3>(k, s); break;
+    case APTP_TILE_DMA3_64x128: launch_tile_dma<64, 128, 3>(k, s); break;
+    case APTP_TILE_DMA3_64x160: launch_tile_dma<64, 160, 3>(k, s); break;
+    case APTP_TILE_DMA3_128x64: launch_tile_dma<128, 64, 3>(k, s); break;
+    case APTP_TILE_DMA3_64x64: launch_tile_dma<64, 64, 3>(k, s); break;
     default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
   }
   APTP_LAUNCH_CHECK();

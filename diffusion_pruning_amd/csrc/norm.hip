@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
   const int r0 = (int)(((int64_t)p.HW * chunk) / gridDim.x), r1 = (int)(((int64_t)p.HW * (chunk + 1)) / gridDim.x);
   const __bf16* xb = p.x + ((int64_t)b * p.HW) * p.ldx;
   __bf16* yb = p.y + ((int64_t)b * p.HW) * p.ldy;
-  constexpr int U = 2;
+  constexpr int U = (NP == 1) ? 4 : 2;   // rows in flight per thread (x2 with the software pipeline below)
   u32x4 q[U][NP];
   auto load_rows = [&](int r) {
 #pragma unroll
@@ -308,9 +308,9 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   k.RPAR = 256 / k.TPR;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid1(k.nchunk, p->B);
-  int nchunk2 = p->HW / 16;   // >= 16 rows per apply workgroup
+  int nchunk2 = p->HW / 16;   // >= 16 rows per apply workgroup, up to 8 resident workgroups per CU
   if (nchunk2 < 1) nchunk2 = 1;
-  if (nchunk2 > 128) nchunk2 = 128;
+  if (nchunk2 > 512) nchunk2 = 512;
   dim3 grid2(nchunk2, p->B);
   if (CO <= 256) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);

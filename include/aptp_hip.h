@@ -89,7 +89,10 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        APTP_TILE_128x64 = 5, APTP_TILE_64x64 = 6,
        /* same tiles, operands copied global->LDS by LDS-DMA instead of through registers */
        APTP_TILE_DMA_128x128 = 7, APTP_TILE_DMA_128x160 = 8, APTP_TILE_DMA_64x128 = 9, APTP_TILE_DMA_64x160 = 10,
-       APTP_TILE_DMA_128x64 = 11, APTP_TILE_DMA_64x64 = 12 };
+       APTP_TILE_DMA_128x64 = 11, APTP_TILE_DMA_64x64 = 12,
+       /* LDS-DMA with a 3-deep ring (DMA two K-steps ahead, counted vmcnt + raw barrier) */
+       APTP_TILE_DMA3_128x128 = 13, APTP_TILE_DMA3_128x160 = 14, APTP_TILE_DMA3_64x128 = 15, APTP_TILE_DMA3_64x160 = 16,
+       APTP_TILE_DMA3_128x64 = 17, APTP_TILE_DMA3_64x64 = 18 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

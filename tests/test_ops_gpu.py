@@ -61,6 +61,20 @@ CONV_CASES = [
     (1, 8, 8, 1280, 1280, 3, 1, 0, 9, 4),
     (2, 16, 16, 192, 128, 1, 1, 0, 7, 1),
     (4, 64, 64, 320, 320, 3, 1, 0, 10, 1),     # full level-64 shape
+    # 3-stage LDS-DMA ring (tiles 13..18): counted vmcnt + raw barrier; short and long K, split-K slices of 1-2 steps
+    (2, 16, 16, 64, 64, 3, 1, 0, 13, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 14, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 16, 1),
+    (2, 16, 16, 128, 128, 3, 2, 0, 15, 1),
+    (2, 8, 8, 128, 128, 3, 1, 1, 15, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 18, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 17, 4),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 15, 4),
+    (2, 16, 16, 64, 128, 1, 1, 0, 13, 1),      # a single K-step
+    (2, 16, 16, 128, 128, 1, 1, 0, 18, 1),     # two K-steps
+    (4, 64, 64, 320, 320, 3, 1, 0, 16, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 14, 1),
+    (4, 32, 32, 1280, 640, 3, 1, 0, 14, 3),
 ]
 
 

@@ -314,14 +314,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
 // directly (global_load_lds_dwordx4, 16 B per lane, destination = wave-uniform base + lane*16) instead of being staged
 // through VGPRs and ds_write_b128.  The LDS image stays lane-linear per wave-instruction (8 rows x 128 B), so the XOR
 // swizzle is applied to the per-lane SOURCE chunk (slot s of row r receives chunk s ^ ((r>>1)&7)) and the same XOR is
-// used by the fragment reads.  Zero padding / ragged tails: an invalid lane reads 16 zero bytes from g_zero16.
+// used by the fragment reads.  Zero padding / ragged tails: an invalid lane streams zeros from g_zero_page.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ uint4 g_zero16[2];
+// 8 KiB of zeros: an invalid (padding / out-of-range) lane streams from here; its pointer is advanced together with the
+// real ones inside a tap, so it must cover one whole channel row (cin_pad * 2 B <= 8064 B, checked on the host).
+__device__ uint4 g_zero_page[512];
 
 // STAGES = 2: double buffer, one __syncthreads() per K-step (the LDS-DMA of step t+1 overlaps the MFMAs of step t).
 // STAGES = 3: ring of three buffers, the DMA runs TWO K-steps ahead; a counted s_waitcnt vmcnt(N) (N = the DMA
 //             instructions this thread issued for the newest tile) retires only the older tile, and a raw s_barrier
 //             (no implicit vmcnt(0)) publishes it, so one tile stays in flight across every barrier.
+// Address generation is incremental: the per-row source pointer is recomputed only when the filter tap changes (every
+// cin_pad/64 K-steps) and otherwise advanced by 128 B per K-step; PMC counters showed the previous per-step
+// recomputation (~115 VALU instructions per K-step per wave) made the loop VALU-issue-bound at 24 % MFMA utilisation.
 template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -333,7 +338,8 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
   __bf16* As = smem;
   __bf16* Bs = smem + STAGES * BM * BK;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases stay scalar
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
@@ -344,7 +350,9 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
 
   const int rowbase = tid >> 3;
   const int schunk = (tid & 7) ^ ((rowbase >> 1) & 7);      // source chunk that lands in this lane's LDS slot
-  const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+  const char* zpage = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+  const char* xbase = reinterpret_cast<const char*>(p.x) + schunk * 16;
+  const bool tail_bad = ((p.ncc - 1) * BK + schunk * 8) >= p.Cin;   // this lane's chunk of the last channel step is padding
   int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS];
 #pragma unroll
   for (int i = 0; i < A_PASS; ++i) {
@@ -356,50 +364,59 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
       a_ix0[i] = ox * p.stride - p.pad;
       a_pix0[i] = b * p.Hin * p.Win;
     } else {
-      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0;
+      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0;       // rows past M: every tap is "padding"
     }
   }
-  const char* b_src[B_PASS];
-#pragma unroll
-  for (int i = 0; i < B_PASS; ++i) {
-    const int n = n0 + rowbase + 32 * i;
-    b_src[i] = n < p.N ? reinterpret_cast<const char*>(p.w) + ((int64_t)n * p.Ktot + schunk * 8) * 2 : nullptr;
-  }
 
-  int l_kt = kt_begin;
   int l_tap = kt_begin / p.ncc;
   int l_cc = kt_begin - l_tap * p.ncc;
   int l_ky = l_tap / p.KW;
   int l_kx = l_tap - l_ky * p.KW;
 
+  const char* a_ptr[A_PASS];
+  auto set_tap = [&](int cc0) {          // (re)compute the row pointers of the current tap, positioned at channel step cc0
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
+      const bool ok = (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE && !(p.zins & (iy | ix));
+      iy >>= p.ups; ix >>= p.ups;
+      const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx) * 2u + (unsigned)cc0 * (BK * 2);   // < 2^31
+      const uint64_t va = reinterpret_cast<uint64_t>(xbase) + off;
+      const uint64_t vz = reinterpret_cast<uint64_t>(zpage) + (unsigned)cc0 * (BK * 2);
+      a_ptr[i] = reinterpret_cast<const char*>(ok ? va : vz);
+    }
+  };
+  const char* b_ptr[B_PASS];
+#pragma unroll
+  for (int i = 0; i < B_PASS; ++i) {
+    int n = n0 + rowbase + 32 * i;
+    n = n < p.N ? n : p.N - 1;            // columns past N accumulate garbage that is never stored
+    b_ptr[i] = reinterpret_cast<const char*>(p.w) + ((int64_t)n * p.Ktot + (int64_t)kt_begin * BK + schunk * 8) * 2;
+  }
+  set_tap(l_cc);
+
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
   auto issue_tile = [&](int buf) {
-    const int c = l_cc * BK + schunk * 8;
-    const bool c_ok = c < p.Cin;
+    const bool last_cc = l_cc == p.ncc - 1;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
-      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE && !(p.zins & (iy | ix));
-      iy >>= p.ups; ix >>= p.ups;
-      const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31
-      const uint64_t va = reinterpret_cast<uint64_t>(p.x) + off, vz = reinterpret_cast<uint64_t>(zsrc);
-      const char* src = reinterpret_cast<const char*>(ok ? va : vz);
+      const char* src = (last_cc && tail_bad) ? zpage : a_ptr[i];
       __bf16* dst = As + (buf * BM + wave * 8 + 32 * i) * BK;      // wave-uniform; lane l lands at dst + l*16 B
       __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+      a_ptr[i] += BK * 2;
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      const uint64_t vb = reinterpret_cast<uint64_t>(b_src[i]) + (unsigned)l_kt * (unsigned)(BK * 2);
-      const char* src = reinterpret_cast<const char*>(b_src[i] ? vb : reinterpret_cast<uint64_t>(zsrc));
       __bf16* dst = Bs + (buf * BN + wave * 8 + 32 * i) * BK;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr)b_ptr[i], (lds_ptr)dst, 16, 0, 0);
+      b_ptr[i] += BK * 2;
     }
-    ++l_kt;
-    if (++l_cc == p.ncc) {
+    if (++l_cc == p.ncc) {               // next tap (wave-uniform branch)
       l_cc = 0;
       if (++l_kx == p.KW) { l_kx = 0; ++l_ky; }
+      set_tap(0);
     }
   };
 
@@ -612,6 +629,7 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * 2;
   const int64_t wb = (int64_t)p->N * k.Ktot * 2;
   APTP_CHECK(xb < (1ll << 31) && wb < (1ll << 31), "conv_gemm: operand larger than 2 GiB");
+  APTP_CHECK(p->cin_pad * 2 <= 8064, "conv_gemm: Cin too large for the zero page (max 4032 channels)");
   k.x_bytes = (int)xb; k.w_bytes = (int)wb;
   return APTP_OK;
 }

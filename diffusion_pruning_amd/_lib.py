@@ -103,6 +103,18 @@ class GroupNormBwdParams(Structure):
         ("eps", c_float), ("silu", c_int32),
         ("fwd_stats", c_void_p),
         ("workspace", c_void_p),
+        ("pgrad_partial", c_void_p),
+    ]
+
+
+class ColsumParams(Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("rows", c_int32), ("C", c_int32), ("partial", c_void_p)]
+
+
+class LayerNormPgradParams(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64),
+        ("rows", c_int32), ("C", c_int32), ("eps", c_float), ("partial", c_void_p),
     ]
 
 
@@ -146,6 +158,8 @@ EXPORTS = [
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),
     ("aptp_layernorm_bwd", c_int, [POINTER(LayerNormBwdParams), c_void_p]),
     ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),
+    ("aptp_colsum", c_int, [POINTER(ColsumParams), c_void_p]),
+    ("aptp_layernorm_pgrad", c_int, [POINTER(LayerNormPgradParams), c_void_p]),
     ("aptp_last_error", c_char_p, []),
     ("aptp_version", c_int, []),
 ]

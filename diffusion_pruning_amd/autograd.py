@@ -178,3 +178,119 @@ def depth_lerp(x_in: torch.Tensor, out: torch.Tensor, d: torch.Tensor) -> torch.
         dm = dm.repeat(B // dm.shape[0])
     dm = dm.view(B, *([1] * (out.dim() - 1)))
     return ((1.0 - dm) * x_in.float() + dm * out.float()).to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Fine-tuning variants: the same ops with WEIGHT gradients.  The trainable tensors are the fp32 masters in
+# diffusers' layout; a pruned expert computes on compacted packs, so parameter gradients are produced in the compact
+# shape (wgrad = the implicit-GEMM kernel on transposed operands, bias = column sums, norm affine = the backward
+# kernels' per-channel partials) and scattered into the live rows / columns of the full-shape ``.grad``.
+# ------------------------------------------------------------------------------------------------------------------
+def _scatter_rows(full_like: torch.Tensor, vals: torch.Tensor, idx: Optional[torch.Tensor]) -> torch.Tensor:
+    if idx is None:
+        return vals.to(full_like.dtype).reshape(full_like.shape)
+    g = torch.zeros_like(full_like)
+    g[idx] = vals.to(full_like.dtype)
+    return g
+
+
+class ConvWFn(Function):
+    """y = conv(x, W[live_out][:, live_in]) + b[live_out];  grads: dx, dW (scattered), db (scattered)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pw: PackedWeight, get_bwd, stride: int, pad: int, ups: int, out_f32: bool,
+                live_out: Optional[torch.Tensor], live_in: Optional[torch.Tensor]):
+        tokens = x.dim() == 3
+        xin = x.unsqueeze(2) if tokens else x
+        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32)
+        ctx.save_for_backward(x, weight, bias if bias is not None else weight.new_zeros(0), live_out if live_out is not None else
+                              torch.zeros(0, dtype=torch.long, device=x.device),
+                              live_in if live_in is not None else torch.zeros(0, dtype=torch.long, device=x.device))
+        ctx.meta = (pw, get_bwd, stride, pad, ups, tokens, bias is not None, live_out is not None, live_in is not None)
+        return y.squeeze(2) if tokens else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, live_out, live_in = ctx.saved_tensors
+        pw, get_bwd, stride, pad, ups, tokens, has_bias, has_lo, has_li = ctx.meta
+        dy = _c(dy.to(torch.bfloat16))
+        dx = dW = db = None
+        k = pw.KH
+        if ctx.needs_input_grad[0]:
+            dy4 = dy.unsqueeze(2) if tokens else dy
+            pwb = get_bwd()
+            if stride == 2:
+                dx = ops.conv_gemm(dy4, pwb, stride=1, pad=k - 1 - pad, ups=2)
+            else:
+                dx = ops.conv_gemm(dy4, pwb, stride=1, pad=k - 1 - pad)
+                if ups == 1:
+                    B, H2, W2, C = dx.shape
+                    dx = dx.view(B, H2 // 2, 2, W2 // 2, 2, C).float().sum(dim=(2, 4)).to(torch.bfloat16)
+            dx = dx.squeeze(2) if tokens else dx
+        n_live = live_out.numel() if has_lo else weight.shape[0]
+        c_live = live_in.numel() if has_li else weight.shape[1]
+        if ctx.needs_input_grad[1]:
+            g = ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups)            # [Npad, taps, Cpad] fp32
+            g = g[:n_live, :, :c_live].permute(0, 2, 1).reshape(n_live, c_live, pw.KH, pw.KW)
+            if weight.dim() == 2:
+                g = g.reshape(n_live, c_live)
+            if has_lo or has_li:
+                full = torch.zeros_like(weight)
+                ro = live_out if has_lo else torch.arange(weight.shape[0], device=weight.device)
+                ci = live_in if has_li else torch.arange(weight.shape[1], device=weight.device)
+                full[ro[:, None], ci[None, :]] = g.to(weight.dtype)
+                dW = full
+            else:
+                dW = g.to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _scatter_rows(bias, ops.colsum(dy)[:n_live], live_out if has_lo else None)
+        return dx, dW, db, None, None, None, None, None, None, None, None
+
+
+def conv_w(x, wparam, bparam, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None):
+    pad = pw.KH // 2 if pad is None else pad
+    return ConvWFn.apply(x, wparam, bparam, pw, get_bwd, stride, pad, ups, out_f32, live_out, live_in)
+
+
+class GroupNormWFn(Function):
+    """GroupNorm(+SiLU) with trainable affine; `live` = channel indices of a compacted tensor (norm2 of a pruned resnet)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma_p, beta_p, gamma, beta, groups: int, eps: float, silu: bool, C: int, live: Optional[torch.Tensor]):
+        y, stats = ops.groupnorm(x, gamma, beta, groups, eps, silu, C=C, keep_stats=True)
+        ctx.save_for_backward(x, gamma, beta, stats, gamma_p, live if live is not None else torch.zeros(0, dtype=torch.long, device=x.device))
+        ctx.meta = (groups, eps, silu, C, live is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats, gamma_p, live = ctx.saved_tensors
+        groups, eps, silu, C, has_live = ctx.meta
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        res = ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, C=C, want_pgrad=want)
+        if not want:
+            return res, None, None, None, None, None, None, None, None, None
+        dx, dgamma, dbeta = res
+        idx = live if has_live else None
+        return dx, _scatter_rows(gamma_p, dgamma, idx), _scatter_rows(gamma_p, dbeta, idx), None, None, None, None, None, None, None
+
+
+class LayerNormWFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma_p, beta_p, gamma, beta, eps: float):
+        x = _c(x)
+        y = ops.layernorm(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, gamma_p)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, gamma_p = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.layernorm_bwd(x, dy, gamma, ctx.eps)
+        dg = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dgamma, dbeta = ops.layernorm_pgrad(x, dy, ctx.eps)
+            dg, db = dgamma.to(gamma_p.dtype), dbeta.to(gamma_p.dtype)
+        return dx, dg, db, None, None, None

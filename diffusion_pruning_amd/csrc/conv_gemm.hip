@@ -629,7 +629,6 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * 2;
   const int64_t wb = (int64_t)p->N * k.Ktot * 2;
   APTP_CHECK(xb < (1ll << 31) && wb < (1ll << 31), "conv_gemm: operand larger than 2 GiB");
-  APTP_CHECK(p->cin_pad * 2 <= 8064, "conv_gemm: Cin too large for the zero page (max 4032 channels)");
   k.x_bytes = (int)xb; k.w_bytes = (int)wb;
   return APTP_OK;
 }
@@ -677,6 +676,11 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   hipStream_t s = (hipStream_t)stream;
   int t = pick_tile(p, k.M);
   if (t < 0 || t >= kNumTiles) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
+  if (t >= APTP_TILE_DMA_128x128 && p->cin_pad * 2 > 8064) {
+    // the LDS-DMA variants stream padding lanes from an 8 KiB zero page that must cover one channel row
+    aptp_set_error("conv_gemm: LDS-DMA tiles need Cin <= 4032 (got cin_pad %d)", p->cin_pad);
+    return APTP_EINVAL;
+  }
   if (k.act == APTP_ACT_GEGLU && (kTiles[t].bn == 160)) {
     aptp_set_error("conv_gemm: GEGLU cannot use a 160-wide tile");
     return APTP_EINVAL;

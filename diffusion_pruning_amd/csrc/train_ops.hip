@@ -212,6 +212,7 @@ struct GnBwdK {
   const float* gamma; const float* beta; float eps; int silu;
   const float* fstats;   // forward partials [B, nchunk, G, 2] (sum, sumsq)
   float* bpart;          // backward partials [B, nchunk, G, 2] (S1, S2)
+  float* pgrad;          // optional per-channel partials [B, nchunk, C, 2] (sum dz, sum dz*xh) -> dbeta, dgamma
 };
 
 __device__ __forceinline__ void fold_forward_stats(const GnBwdK& p, int b, int tid, float* mean_s, float* rstd_s) {
@@ -300,9 +301,8 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdK p) {
               const float sg = sigmoid_f(z);
               dz *= sg * (1.0f + z * (1.0f - sg));
             }
-            const float dxh = dz * ga[pg][e];
-            if (APPLY) dxv[e] = rs[pg][e] * (dxh - m1[pg][e] - xh * m2[pg][e]);
-            else { a1[pg][e] += dxh; a2v[pg][e] += dxh * xh; }
+            if (APPLY) dxv[e] = rs[pg][e] * (dz * ga[pg][e] - m1[pg][e] - xh * m2[pg][e]);
+            else { a1[pg][e] += dz; a2v[pg][e] += dz * xh; }
           }
           if (APPLY) *reinterpret_cast<u32x4*>(p.dx + (row0 + r) * p.lddx + o * 8) = pack8(dxv);
         }
@@ -325,7 +325,23 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdK p) {
       }
     }
     __syncthreads();
-    fold_channels_to_groups(k, red, 2, CP, tid, p.bpart + ((int64_t)b * k.nchunk + chunk) * k.G * 2);
+    // fold the RPAR row lanes per channel; the per-channel sums are the affine-parameter gradients' partials, and,
+    // weighted by gamma, the per-group sums S1 = sum dxh, S2 = sum dxh*xh
+    for (int c = tid; c < k.C; c += 256) {
+      float v0 = 0.f, v1 = 0.f;
+      for (int rr = 0; rr < k.RPAR; ++rr) { v0 += red[0][rr * CP + c]; v1 += red[1][rr * CP + c]; }
+      if (p.pgrad) {
+        float* o = p.pgrad + (((int64_t)b * k.nchunk + chunk) * k.C + c) * 2;
+        o[0] = v0; o[1] = v1;
+      }
+      const float gmm = p.gamma[c];
+      red[0][c] = v0 * gmm;
+      red[1][c] = v1 * gmm;
+    }
+    __syncthreads();
+    RowK k1 = k;
+    k1.RPAR = 1;
+    fold_channels_to_groups(k1, red, 2, CP, tid, p.bpart + ((int64_t)b * k.nchunk + chunk) * k.G * 2);
   }
 }
 
@@ -405,6 +421,124 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdK p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Column sums of a [rows, C] bf16 matrix (bias gradients): partial[chunk, c] = sum over the rows of the chunk.
+// ------------------------------------------------------------------------------------------------------------
+struct ColsumK { const __bf16* x; int64_t ldx; int rows, C, CO, nchunk, TPR, RPAR; float* partial; };
+
+template <int NP>
+__global__ __launch_bounds__(256) void colsum_kernel(const ColsumK p) {
+  __shared__ float red[6144];
+  const int tid = threadIdx.x, chunk = blockIdx.x;
+  const int r0 = (int)(((int64_t)p.rows * chunk) / p.nchunk), r1 = (int)(((int64_t)p.rows * (chunk + 1)) / p.nchunk);
+  const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
+  const bool active = rl < p.RPAR;
+  float acc[NP][8];
+#pragma unroll
+  for (int pg = 0; pg < NP; ++pg)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[pg][e] = 0.f;
+  if (active) {
+    for (int r = r0 + rl; r < r1; r += p.RPAR) {
+#pragma unroll
+      for (int pg = 0; pg < NP; ++pg) {
+        const int o = ot + pg * 256;
+        if (o < p.CO) {
+          float f[8];
+          unpack8(*reinterpret_cast<const u32x4*>(p.x + (int64_t)r * p.ldx + o * 8), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[pg][e] += f[e];
+        }
+      }
+    }
+  }
+  const int CP = p.TPR * 8 * NP;
+  if (active) {
+#pragma unroll
+    for (int pg = 0; pg < NP; ++pg) {
+      const int o = ot + pg * 256;
+      if (o < p.CO) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rl * CP + o * 8 + e] = acc[pg][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < p.C; c += 256) {
+    float v = 0.f;
+    for (int rr = 0; rr < p.RPAR; ++rr) v += red[rr * CP + c];
+    p.partial[(int64_t)chunk * p.C + c] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm affine-parameter gradients: partial[chunk, c, 0] = sum_rows dy (dbeta), [.., 1] = sum_rows dy*xh (dgamma).
+// One wave per row (statistics by wave reduction), per-lane channel accumulators, 4 waves folded through LDS.
+// ------------------------------------------------------------------------------------------------------------
+struct LnPgK { const __bf16* x; int64_t ldx; const __bf16* dy; int64_t lddy; int rows, C, CO, nchunk; float eps; float* partial; };
+
+template <int NO>
+__global__ __launch_bounds__(256) void ln_pgrad_kernel(const LnPgK p) {
+  __shared__ float red[2][4][2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, chunk = blockIdx.x;
+  const int r0 = (int)(((int64_t)p.rows * chunk) / p.nchunk), r1 = (int)(((int64_t)p.rows * (chunk + 1)) / p.nchunk);
+  float ab[NO][8], ag[NO][8];
+#pragma unroll
+  for (int i = 0; i < NO; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ab[i][e] = 0.f; ag[i][e] = 0.f; }
+  for (int row = r0 + wave; row < r1; row += 4) {
+    float x[NO][8], d[NO][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int o = lane + 64 * i;
+      if (o < p.CO) {
+        unpack8(*reinterpret_cast<const u32x4*>(p.x + (int64_t)row * p.ldx + o * 8), x[i]);
+        unpack8(*reinterpret_cast<const u32x4*>(p.dy + (int64_t)row * p.lddy + o * 8), d[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += x[i][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[i][e] = 0.f; d[i][e] = 0.f; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)p.C;
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int o = lane + 64 * i;
+      if (o < p.CO) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float c = x[i][e] - mean; vs += c * c; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vs += __shfl_xor(vs, off);
+    const float rstd = rsqrtf(vs / (float)p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < NO; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ab[i][e] += d[i][e]; ag[i][e] += d[i][e] * (x[i][e] - mean) * rstd; }
+  }
+#pragma unroll
+  for (int i = 0; i < NO; ++i) {
+    const int o = lane + 64 * i;
+    if (o < p.CO) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[0][wave][o * 8 + e] = ab[i][e]; red[1][wave][o * 8 + e] = ag[i][e]; }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float* o = p.partial + ((int64_t)chunk * p.C + c) * 2;
+    o[0] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    o[1] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  }
+}
+
 int fill_rowk(RowK& k, int B, int HW, int C, int G, const char* what) {
   APTP_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 128 && C % G == 0, "%s: bad extents (B=%d HW=%d C=%d G=%d)", what, B, HW, C, G);
   k.B = B; k.HW = HW; k.C = C; k.G = G; k.cg = C / G; k.CO = (C + 7) / 8;
@@ -474,7 +608,7 @@ extern "C" int aptp_groupnorm_bwd(const AptpGroupNormBwdParams* p, aptp_stream_t
   APTP_CHECK(p->ldx % 8 == 0 && p->lddy % 8 == 0 && p->lddx % 8 == 0 && ALIGN16(p->x) && ALIGN16(p->dy) && ALIGN16(p->dx), "groupnorm_bwd: alignment");
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dx = (__bf16*)p->dx; k.lddx = p->lddx;
   k.gamma = p->gamma; k.beta = p->beta; k.eps = p->eps; k.silu = p->silu;
-  k.fstats = p->fwd_stats; k.bpart = (float*)p->workspace;
+  k.fstats = p->fwd_stats; k.bpart = (float*)p->workspace; k.pgrad = p->pgrad_partial;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(k.r.nchunk, p->B);
   if (k.r.CO <= 256) {
@@ -502,6 +636,39 @@ extern "C" int aptp_layernorm_bwd(const AptpLayerNormBwdParams* p, aptp_stream_t
     case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, s, k); break;
     case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, dim3(256), 0, s, k); break;
     default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, k); break;
+  }
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}
+
+extern "C" int aptp_colsum(const AptpColsumParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->x && p->partial, "colsum: null pointer");
+  APTP_CHECK(p->rows > 0 && p->C > 0 && p->C % 8 == 0 && p->C <= 6144 && p->ldx % 8 == 0 && ALIGN16(p->x), "colsum: C multiple of 8 (<= 6144), ld multiple of 8");
+  ColsumK k;
+  k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.rows = p->rows; k.C = p->C; k.CO = p->C / 8;
+  k.nchunk = aptp_groupnorm_nchunk(p->rows); k.TPR = k.CO < 256 ? k.CO : 256; k.RPAR = 256 / k.TPR; k.partial = p->partial;
+  dim3 grid(k.nchunk);
+  hipStream_t s = (hipStream_t)stream;
+  if (k.CO <= 256) hipLaunchKernelGGL(colsum_kernel<1>, grid, dim3(256), 0, s, k);
+  else if (k.CO <= 512) hipLaunchKernelGGL(colsum_kernel<2>, grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL(colsum_kernel<3>, grid, dim3(256), 0, s, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}
+
+extern "C" int aptp_layernorm_pgrad(const AptpLayerNormPgradParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->x && p->dy && p->partial, "layernorm_pgrad: null pointer");
+  APTP_CHECK(p->rows > 0 && p->C > 0 && p->C % 8 == 0 && p->C <= 2048 && p->ldx % 8 == 0 && p->lddy % 8 == 0 && ALIGN16(p->x) && ALIGN16(p->dy), "layernorm_pgrad: C multiple of 8 (<= 2048)");
+  LnPgK k;
+  k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy;
+  k.rows = p->rows; k.C = p->C; k.CO = p->C / 8; k.nchunk = aptp_groupnorm_nchunk(p->rows); k.eps = p->eps; k.partial = p->partial;
+  dim3 grid(k.nchunk);
+  hipStream_t s = (hipStream_t)stream;
+  switch ((k.CO + 63) / 64) {
+    case 1: hipLaunchKernelGGL(ln_pgrad_kernel<1>, grid, dim3(256), 0, s, k); break;
+    case 2: hipLaunchKernelGGL(ln_pgrad_kernel<2>, grid, dim3(256), 0, s, k); break;
+    case 3: hipLaunchKernelGGL(ln_pgrad_kernel<3>, grid, dim3(256), 0, s, k); break;
+    default: hipLaunchKernelGGL(ln_pgrad_kernel<4>, grid, dim3(256), 0, s, k); break;
   }
   APTP_LAUNCH_CHECK();
   return APTP_OK;

@@ -15,7 +15,8 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, GateBwdParams,
-                   GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams)
+                   GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
+                   ColsumParams, LayerNormPgradParams)
 
 BK = 64
 
@@ -409,20 +410,59 @@ def geglu_bwd(hg: torch.Tensor, dout: torch.Tensor, gate: Optional[torch.Tensor]
 
 
 def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
-                  silu: bool, stats: torch.Tensor) -> torch.Tensor:
+                  silu: bool, stats: torch.Tensor, C: Optional[int] = None, want_pgrad: bool = False):
+    """dx (and, with want_pgrad, (dgamma, dbeta) fp32 [C]) of GroupNorm(+SiLU); C = real channel count when the
+    tensor is padded to a multiple of 8."""
     lib = _lib.load()
-    B, HW, C, ldx = _rows(x)
+    B, HW, Cp, ldx = _rows(x)
+    C = Cp if C is None else C
     _, _, _, lddy = _rows(dy)
-    dx = torch.empty(*x.shape, dtype=torch.bfloat16, device=x.device)
+    dx = torch.zeros(*x.shape, dtype=torch.bfloat16, device=x.device) if C != Cp else \
+        torch.empty(*x.shape, dtype=torch.bfloat16, device=x.device)
     p = GroupNormBwdParams()
-    p.x, p.ldx, p.dy, p.lddy, p.dx, p.lddx = x.data_ptr(), ldx, dy.data_ptr(), lddy, dx.data_ptr(), C
+    p.x, p.ldx, p.dy, p.lddy, p.dx, p.lddx = x.data_ptr(), ldx, dy.data_ptr(), lddy, dx.data_ptr(), Cp
     p.B, p.HW, p.C, p.groups = B, HW, C, groups
     p.gamma, p.beta, p.eps, p.silu = gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
     p.fwd_stats = stats.data_ptr()
     ws = torch.empty_like(stats)
     p.workspace = ws.data_ptr()
+    part = None
+    if want_pgrad:
+        part = torch.empty(B, stats.shape[1], C, 2, dtype=torch.float32, device=x.device)
+        p.pgrad_partial = part.data_ptr()
     _lib.check(lib.aptp_groupnorm_bwd(ctypes.byref(p), _stream()), "aptp_groupnorm_bwd")
+    if want_pgrad:
+        pg = part.sum(dim=(0, 1))
+        return dx, pg[:, 1].contiguous(), pg[:, 0].contiguous()
     return dx
+
+
+def layernorm_pgrad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5):
+    """(dgamma, dbeta) fp32 [C] of LayerNorm over the last dim."""
+    lib = _lib.load()
+    B, L, C, ldx = _rows(x)
+    _, _, _, lddy = _rows(dy)
+    nchunk = lib.aptp_groupnorm_nchunk(B * L)
+    part = torch.empty(nchunk, C, 2, dtype=torch.float32, device=x.device)
+    p = LayerNormPgradParams()
+    p.x, p.ldx, p.dy, p.lddy, p.rows, p.C, p.eps, p.partial = x.data_ptr(), ldx, dy.data_ptr(), lddy, B * L, C, eps, part.data_ptr()
+    _lib.check(lib.aptp_layernorm_pgrad(ctypes.byref(p), _stream()), "aptp_layernorm_pgrad")
+    pg = part.sum(dim=0)
+    return pg[:, 1].contiguous(), pg[:, 0].contiguous()
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a bf16 [..., C] tensor with contiguous last dim and uniform row stride (bias gradients)."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    rows = x2.shape[0]
+    nchunk = lib.aptp_groupnorm_nchunk(rows)
+    part = torch.empty(nchunk, C, dtype=torch.float32, device=x.device)
+    p = ColsumParams()
+    p.x, p.ldx, p.rows, p.C, p.partial = x2.data_ptr(), (x2.stride(0) if rows > 1 else C), rows, C, part.data_ptr()
+    _lib.check(lib.aptp_colsum(ctypes.byref(p), _stream()), "aptp_colsum")
+    return part.sum(dim=0)
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -453,3 +493,52 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional
     p.scale = (1.0 / 8.0) if scale is None else scale
     _lib.check(lib.aptp_attention_bwd(ctypes.byref(p), _stream()), "aptp_attention_bwd")
     return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# weight gradients (expert fine-tuning): dW[n, tap, c] = sum_m dy[m, n] * x[pix(m, tap), c]
+# The reduction runs over pixels, so both operands are presented K-major (transposed) to the SAME implicit-GEMM kernel:
+# "activations" = dy^T [N rows, M], "weights" = im2col(x)^T [taps*C rows, M]; split-K spreads the long reduction over
+# the chip.  The transposes / im2col are data-movement glue (strided copies); the contraction is aptp_conv_gemm.
+# ------------------------------------------------------------------------------------------------------------------
+def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int) -> torch.Tensor:
+    """x [B,H,W,C] bf16 -> [KH*KW*C, M] (M = B*Hout*Wout), taps-major then channels, matching the packed weight order."""
+    B, H, W, C = x.shape
+    if ups == 1:
+        x = x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+        H, W = 2 * H, 2 * W
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    if KH == 1 and KW == 1 and stride == 1 and pad == 0:
+        return x.reshape(B * H * W, C).t().contiguous()
+    xp = torch.nn.functional.pad(x, (0, 0, pad, pad, pad, pad))
+    cols = torch.empty(KH * KW, C, B, Ho, Wo, dtype=x.dtype, device=x.device)
+    for ky in range(KH):
+        for kx in range(KW):
+            v = xp[:, ky:ky + (Ho - 1) * stride + 1:stride, kx:kx + (Wo - 1) * stride + 1:stride, :]
+            cols[ky * KW + kx].copy_(v.permute(3, 0, 1, 2))
+    return cols.reshape(KH * KW * C, B * Ho * Wo)
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int = 1, pad: int = 0, ups: int = 0) -> torch.Tensor:
+    """Weight gradient of y = conv(x, w): returns fp32 [N, KH*KW, C] (the packed-weight order, unpadded).
+    x [B,H,W,C] (or tokens [B,L,C] with KH=KW=1), dy [B,Ho,Wo,N] (or [B,L,N]); both bf16."""
+    if x.dim() == 3:
+        x, dy = x.unsqueeze(2), dy.unsqueeze(2)
+    C, N = x.shape[-1], dy.shape[-1]
+    xt = _im2col_T(x, KH, KW, stride, pad, ups)                   # [K, M]
+    K, M = xt.shape
+    dyt = dy.reshape(M, N).t().contiguous()                         # [N, M]
+    Mp = round_up(M, BK)
+    if Mp != M:                                                     # ragged reduction length (e.g. 4*77 text tokens)
+        xt = torch.nn.functional.pad(xt, (0, Mp - M))
+        dyt = torch.nn.functional.pad(dyt, (0, Mp - M))
+    Kp = round_up(K, 8)
+    if Kp != K:
+        xt = torch.nn.functional.pad(xt, (0, 0, 0, Kp - K))
+    pw = PackedWeight(xt.view(Kp, 1, Mp), None, Kp, Mp, 1, 1)
+    Np = round_up(N, 8)
+    if Np != N:
+        dyt = torch.nn.functional.pad(dyt, (0, 0, 0, Np - N))
+    out = conv_gemm(dyt.view(1, Np, 1, Mp), pw, pad=0, out_f32=True)            # [1, Np, 1, Kp] fp32
+    return out.view(Np, Kp)[:N, :K].reshape(N, KH * KW, C)

@@ -213,3 +213,75 @@ def synthetic_batch(batch: int, latent: int, device, seed: int = 1234, cross_dim
         "mpnet_embeddings": (0.05 * torch.randn(batch, text_dim, generator=g)).to(device),
         "timesteps": torch.randint(0, 1000, (batch,), generator=g).to(device),
     }
+
+
+@dataclass
+class FinetuneLossConfig:
+    """configs/finetuning/sd-2-1_cc3m.yaml:86-95"""
+    snr_gamma: Optional[float] = 5.0
+    prediction_type: str = "v_prediction"
+    diffusion_weight: float = 0.01
+    block_weight: float = 0.5
+    distillation_weight: float = 0.5
+
+
+class FineTunerStep:
+    """Expert fine-tuning step (pdm/training/trainer.py:1683-1765, config 5): teacher = dense ungated U-Net under
+    no_grad, student = physically pruned expert (UNet2DConditionModelPruned) with every parameter trainable;
+    loss = w_d * minSNR-MSE + w_b * block-MSE + w_k * distill-MSE.  Experts never communicate ("one expert per GPU" =
+    independent processes, scripts/aptp/finetune.py:27-28); `allreduce_mean_grads` covers the optional data-parallel
+    case."""
+
+    def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None):
+        self.student, self.teacher = student, teacher
+        self.cfg = cfg or FinetuneLossConfig()
+        self.schedule = schedule or NoiseSchedule()
+        self.acts_s: Dict[str, torch.Tensor] = {}
+        self.acts_t: Dict[str, torch.Tensor] = {}
+        self._hooks = []
+        for model, acts in ((student, self.acts_s), (teacher, self.acts_t)):
+            def mk(name, residuals_present, acts=acts):
+                if residuals_present:
+                    return lambda m, i, o: acts.__setitem__(name, o[0])
+                return lambda m, i, o: acts.__setitem__(name, o)
+            for i, b in enumerate(model.down_blocks):
+                self._hooks.append(b.register_forward_hook(mk("d" + str(i), True)))
+            self._hooks.append(model.mid_block.register_forward_hook(mk("m", False)))
+            for i, b in enumerate(model.up_blocks):
+                self._hooks.append(b.register_forward_hook(mk("u" + str(i), False)))
+
+    def step(self, noisy_latents, timesteps, encoder_hidden_states, target):
+        cfg = self.cfg
+        with torch.no_grad():
+            full_pred = self.teacher(noisy_latents, timesteps, encoder_hidden_states).sample.detach()      # :1726-1727
+        model_pred = self.student(noisy_latents, timesteps, encoder_hidden_states).sample                  # :1729
+        if cfg.snr_gamma is None:
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+        else:
+            snr = compute_snr(self.schedule, timesteps)
+            if cfg.prediction_type == "v_prediction":
+                snr = snr + 1
+            w = torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
+            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
+        diff_loss = loss.detach().clone()
+        loss = loss * cfg.diffusion_weight
+        block_loss = torch.zeros((), device=model_pred.device)
+        if cfg.block_weight > 0:
+            for k in self.acts_s:
+                block_loss = block_loss + F.mse_loss(self.acts_s[k].float(), self.acts_t[k].detach().float(), reduction="mean")
+            block_loss = block_loss / len(self.acts_s)
+            loss = loss + cfg.block_weight * block_loss
+        distillation_loss = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")
+        loss = loss + cfg.distillation_weight * distillation_loss
+        return {"loss": loss, "diff_loss": diff_loss, "distillation_loss": distillation_loss.detach(),
+                "block_loss": block_loss.detach()}
+
+    def train_step(self, optimizer, batch: dict):
+        optimizer.zero_grad(set_to_none=True)
+        out = self.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"], batch["target"])
+        out["loss"].backward()
+        allreduce_mean_grads([p for p in self.student.parameters() if p.requires_grad])
+        optimizer.step()
+        self.student.invalidate_plans()       # the bf16 packs are rebuilt from the updated fp32 masters
+        return out

@@ -175,6 +175,7 @@ class ResnetBlock2DWidthGated(nn.Module):
             live, dead, k_live = None, None, self.groups
         c_live = k_live * cg
         pl["k_live"], pl["c_live"], pl["c_pad"] = k_live, c_live, ops.round_up(c_live, 8)
+        pl["live"] = None if live is None else live.to(dev)
         pl["w1"] = ops.pack_weight(self.conv1.weight.detach(), self.conv1.bias.detach(), out_idx=live, device=dev)
         # time_emb_proj rows (+bias) are gathered the same way and batched by the model into one GEMM
         wt, bt = _f32(self.time_emb_proj.weight), _f32(self.time_emb_proj.bias)
@@ -253,8 +254,53 @@ class ResnetBlock2DWidthGated(nn.Module):
                 out = AG.depth_lerp(x_in, out, d.to(device=dev, dtype=torch.float32))
         return _nchw(out)
 
+    def _sel_bwd_pack(self, pl, name, param, dev, live_out=None, live_in=None):
+        def get():
+            key = name + "_bwd"
+            if key not in pl:
+                w = param.detach()
+                if live_out is not None:
+                    w = w[live_out]
+                if live_in is not None:
+                    w = w[:, live_in]
+                pl[key] = ops.pack_weight_dgrad(w, device=dev)
+            return pl[key]
+        return get
+
+    def _forward_ft(self, x, temb):
+        """Fine-tuning path (FineTuner.step, trainer.py:1683-1765): weights require grad; a pruned expert runs on its
+        compacted packs and parameter gradients are scattered back into the live rows / columns of the masters."""
+        from . import autograd as AG
+        dev = x.device
+        pl = self.plan(dev)
+        B, H, W, Cin = x.shape
+        x_in = x[..., :Cin - self.skip_connection_dim] if (self.depth_gated and self.is_input_concatenated) else x
+        if self.depth_gated and (self.dropped or self._depth_state()[0] == 0.0):
+            return _nchw(x_in)
+        live = pl["live"]
+        a1 = AG.GroupNormWFn.apply(x, self.norm1.weight, self.norm1.bias, pl["g1"], pl["b1"], self.groups, self.eps, True, Cin, None)
+        if "temb_pw" not in pl:
+            pl["temb_pw"] = ops.pack_weight(pl["temb_w"], pl["temb_b"], device=dev)
+        emb_silu = temb.emb_silu if isinstance(temb, TembBundle) else torch.nn.functional.silu(temb.float()).to(torch.bfloat16)
+        tproj = AG.conv_w(emb_silu[None], self.time_emb_proj.weight, self.time_emb_proj.bias, pl["temb_pw"],
+                          self._sel_bwd_pack(pl, "temb", self.time_emb_proj.weight, dev, live), pad=0, out_f32=True, live_out=live)[0]
+        h = AG.conv_w(a1, self.conv1.weight, self.conv1.bias, pl["w1"], self._sel_bwd_pack(pl, "w1", self.conv1.weight, dev, live),
+                      live_out=live)
+        h = (h.float() + tproj[:, None, None, :]).to(torch.bfloat16)
+        a2 = AG.GroupNormWFn.apply(h, self.norm2.weight, self.norm2.bias, pl["g2"], pl["b2"], pl["k_live"], self.eps, True,
+                                   pl["c_live"], live)
+        sc = x
+        if self.conv_shortcut is not None:
+            sc = AG.conv_w(x, self.conv_shortcut.weight, self.conv_shortcut.bias, pl["wsc"],
+                           self._sel_bwd_pack(pl, "wsc", self.conv_shortcut.weight, dev), pad=0)
+        out = AG.conv_w(a2, self.conv2.weight, self.conv2.bias, pl["w2"],
+                        self._sel_bwd_pack(pl, "w2", self.conv2.weight, dev, None, live), live_in=live) + sc
+        return _nchw(out)
+
     def forward(self, input_tensor: torch.Tensor, temb, scale: float = 1.0):
         x = _nhwc(input_tensor)
+        if torch.is_grad_enabled() and self.conv1.weight.requires_grad:
+            return self._forward_ft(x, temb)
         if self._needs_autograd(x):
             return self._forward_train(x, temb)
         dev = x.device
@@ -578,6 +624,80 @@ class Transformer2DModelWidthGated(nn.Module):
                 out = AG.depth_lerp(x_tok, out, d.to(device=dev, dtype=torch.float32))
         return _nchw(out.reshape(B, H, W, C))
 
+    def _forward_ft(self, x, encoder_hidden_states):
+        """Fine-tuning path: trainable projections / norms, head- and FF-chunk compaction of a pruned expert."""
+        from . import autograd as AG
+        dev = x.device
+        pl = self.plan(dev)
+        tb = self.transformer_blocks[0]
+        B, H, W, C = x.shape
+        P = H * W
+
+        def bwd(name, param, lo=None, li=None):
+            def get():
+                key = name + "_ftbwd"
+                if key not in pl:
+                    w = param.detach()
+                    if lo is not None:
+                        w = w[lo]
+                    if li is not None:
+                        w = w[:, li]
+                    pl[key] = ops.pack_weight_dgrad(w, device=dev)
+                return pl[key]
+            return get
+
+        def pack(name, param, bias=None, lo=None, li=None, cin_pad_to=8):
+            key = name + "_ft"
+            if key not in pl:
+                pl[key] = ops.pack_weight(param.detach(), None if bias is None else bias.detach(), out_idx=lo, in_idx=li,
+                                          cin_pad_to=cin_pad_to, device=dev)
+            return pl[key]
+
+        def lin(xx, name, mod, lo=None, li=None):
+            b = mod.bias
+            return AG.conv_w(xx, mod.weight, b, pack(name, mod.weight, b, lo, li), bwd(name, mod.weight, lo, li), pad=0,
+                             live_out=lo, live_in=li)
+
+        def live_of(gate, width):
+            m = gate.hard_uniform()
+            if m is None or bool((m == 1).all()):
+                return None, None
+            return _live_index(m, width).to(dev), int(m.sum())
+
+        a = AG.GroupNormWFn.apply(x, self.norm.weight, self.norm.bias, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False, C, None)
+        tok = a.reshape(B, P, C)
+        x_tok = x.reshape(B, P, C)
+        h = lin(tok, "proj_in", self.proj_in)
+        # self attention
+        n = AG.LayerNormWFn.apply(h, tb.norm1.weight, tb.norm1.bias, pl["ln1_g"], pl["ln1_b"], 1e-5)
+        a1 = tb.attn1
+        l1, h1 = live_of(a1.gate, 64)
+        h1 = a1.heads if h1 is None else h1
+        qkv = torch.cat([lin(n, "a1q", a1.to_q, l1), lin(n, "a1k", a1.to_k, l1), lin(n, "a1v", a1.to_v, l1)], dim=-1)
+        o = AG.SelfAttnFn.apply(qkv, h1)
+        h = lin(o, "a1o", a1.to_out[0], None, l1) + h
+        # cross attention
+        n = AG.LayerNormWFn.apply(h, tb.norm2.weight, tb.norm2.bias, pl["ln2_g"], pl["ln2_b"], 1e-5)
+        a2 = tb.attn2
+        l2, h2 = live_of(a2.gate, 64)
+        h2 = a2.heads if h2 is None else h2
+        ehs = encoder_hidden_states.ehs if isinstance(encoder_hidden_states, CtxBundle) else \
+            encoder_hidden_states.to(device=dev, dtype=torch.bfloat16)
+        q = lin(n, "a2q", a2.to_q, l2)
+        kv = torch.cat([lin(ehs, "a2k", a2.to_k, l2), lin(ehs, "a2v", a2.to_v, l2)], dim=-1)
+        o = AG.CrossAttnFn.apply(q, kv, h2)
+        h = lin(o, "a2o", a2.to_out[0], None, l2) + h
+        # feed-forward
+        n = AG.LayerNormWFn.apply(h, tb.norm3.weight, tb.norm3.bias, pl["ln3_g"], pl["ln3_b"], 1e-5)
+        geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
+        lf, _ = live_of(geglu.gate, geglu.dim_out // geglu.gate.width)
+        lo2 = None if lf is None else torch.cat([lf, lf + geglu.dim_out])
+        hg = lin(n, "ff1", geglu.proj, lo2)
+        f = AG.GegluFn.apply(hg, None)
+        h = lin(f, "ff2", lin2, None, lf) + h
+        out = lin(h, "proj_out", self.proj_out) + x_tok
+        return _nchw(out.reshape(B, H, W, C))
+
     # ---- forward --------------------------------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None,
                 class_labels=None, cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None,
@@ -585,6 +705,10 @@ class Transformer2DModelWidthGated(nn.Module):
         if attention_mask is not None or encoder_attention_mask is not None:
             raise NotImplementedError("attention masks are not used on the APTP path (pruning_pipelines.py:796-802)")
         x = _nhwc(hidden_states)
+        if torch.is_grad_enabled() and self.proj_in.weight.requires_grad:
+            if self.depth_gated and (self.dropped or self._depth_state()[0] == 0.0):
+                return self._ret(hidden_states, return_dict)
+            return self._ret(self._forward_ft(x, encoder_hidden_states), return_dict)
         if self._needs_autograd(x) and not (self.depth_gated and self.dropped):
             return self._ret(self._forward_train(x, encoder_hidden_states), return_dict)
         d_hard, d_vec = self._depth_state()
@@ -700,6 +824,9 @@ class Downsample2D(nn.Module):
         if self._pw is None or self._pw.w.device != x.device:
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
             self._pwb = None
+        if torch.is_grad_enabled() and self.conv.weight.requires_grad:
+            from . import autograd as AG
+            return _nchw(AG.conv_w(x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), stride=2, pad=1))
         if torch.is_grad_enabled() and x.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), stride=2, pad=1))
@@ -729,6 +856,9 @@ class Upsample2D(nn.Module):
         if self._pw is None or self._pw.w.device != x.device:
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
             self._pwb = None
+        if torch.is_grad_enabled() and self.conv.weight.requires_grad:
+            from . import autograd as AG
+            return _nchw(AG.conv_w(x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), ups=1))
         if torch.is_grad_enabled() and x.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), ups=1))
@@ -1214,6 +1344,60 @@ class UNet2DConditionModelGated(nn.Module):
         dev = encoder_hidden_states.device
         return self._project_context(encoder_hidden_states, self._batched_packs(dev), dev)
 
+    def _forward_ft(self, sample, timestep, encoder_hidden_states, return_dict):
+        """Forward of the fine-tuning step: every parameter trainable (FineTuner, trainer.py:1529-1540, 1729)."""
+        from . import autograd as AG
+        dev = sample.device
+        B = sample.shape[0]
+        misc = self._misc_packs(dev)
+        for r in self._resnets():
+            r.semantics = self.semantics
+
+        def bwd(name, param):
+            def get():
+                if name not in misc:
+                    misc[name] = ops.pack_weight_dgrad(param.detach(), device=dev)
+                return misc[name]
+            return get
+        timesteps = timestep
+        if not torch.is_tensor(timesteps):
+            timesteps = torch.tensor([timesteps], dtype=torch.int64, device=dev)
+        elif timesteps.dim() == 0:
+            timesteps = timesteps[None].to(dev)
+        timesteps = timesteps.to(dev).expand(B)
+        ang = timesteps.float()[:, None] * misc["freqs"][None, :]
+        t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
+        te = self.time_embedding
+        e1 = AG.conv_w(t_emb[None], te.linear_1.weight, te.linear_1.bias, misc["t1"], bwd("t1_bwd", te.linear_1.weight), pad=0, out_f32=True)
+        e1 = torch.nn.functional.silu(e1).to(torch.bfloat16)
+        e2 = AG.conv_w(e1, te.linear_2.weight, te.linear_2.bias, misc["t2"], bwd("t2_bwd", te.linear_2.weight), pad=0, out_f32=True)
+        temb = TembBundle(emb_silu=torch.nn.functional.silu(e2)[0].to(torch.bfloat16))
+        ctx = CtxBundle(ehs=encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous())
+        x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
+        x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
+        live_in = torch.arange(self.in_channels, device=dev)
+        h = _nchw(AG.conv_w(x, self.conv_in.weight, self.conv_in.bias, misc["conv_in"], bwd("conv_in_bwd", self.conv_in.weight),
+                            live_in=live_in))
+        res_samples = (h,)
+        for blk in self.down_blocks:
+            h, res = blk(hidden_states=h, temb=temb, encoder_hidden_states=ctx)
+            res_samples += res
+        h = self.mid_block(h, temb, encoder_hidden_states=ctx)
+        for blk in self.up_blocks:
+            n_res = len(blk.resnets)
+            res = res_samples[-n_res:]
+            res_samples = res_samples[:-n_res]
+            h = blk(hidden_states=h, temb=temb, res_hidden_states_tuple=res, encoder_hidden_states=ctx)
+        a = AG.GroupNormWFn.apply(_nhwc(h), self.conv_norm_out.weight, self.conv_norm_out.bias, misc["gn_g"], misc["gn_b"],
+                                  self.conv_norm_out.num_groups, self.conv_norm_out.eps, True, self.conv_norm_out.num_channels, None)
+        live_out = torch.arange(self.out_channels, device=dev)
+        y = AG.conv_w(a, self.conv_out.weight, self.conv_out.bias, misc["conv_out"], bwd("conv_out_bwd", self.conv_out.weight),
+                      out_f32=True, live_out=live_out)
+        out = y[..., :self.out_channels].permute(0, 3, 1, 2).to(sample.dtype)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
     # ---- forward (unet_2d_conditional.py:1415-1726) -------------------------------------------------------------------
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
                 timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
@@ -1225,6 +1409,8 @@ class UNet2DConditionModelGated(nn.Module):
             raise NotImplementedError("only the arguments the APTP trainer/pipeline pass are supported")
         dev = sample.device
         B = sample.shape[0]
+        if torch.is_grad_enabled() and self.conv_in.weight.requires_grad:
+            return self._forward_ft(sample, timestep, encoder_hidden_states, return_dict)
         misc = self._misc_packs(dev)
         bp = self._batched_packs(dev)
         out_dtype = sample.dtype

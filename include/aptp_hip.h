@@ -201,6 +201,7 @@ typedef struct {
   float eps; int32_t silu;
   const float* fwd_stats;
   void* workspace;
+  float* pgrad_partial;   /* optional fp32 [B, nchunk, C, 2]: per-channel (sum dz, sum dz*xhat) -> dbeta, dgamma (fine-tuning) */
 } AptpGroupNormBwdParams;
 int aptp_groupnorm_bwd(const AptpGroupNormBwdParams* p, aptp_stream_t stream);
 
@@ -214,6 +215,20 @@ typedef struct {
   float eps;
 } AptpLayerNormBwdParams;
 int aptp_layernorm_bwd(const AptpLayerNormBwdParams* p, aptp_stream_t stream);
+
+/* Column sums of a bf16 [rows, C] matrix (bias gradients): partial fp32 [aptp_groupnorm_nchunk(rows), C]. */
+typedef struct { const void* x; int64_t ldx; int32_t rows, C; float* partial; } AptpColsumParams;
+int aptp_colsum(const AptpColsumParams* p, aptp_stream_t stream);
+
+/* LayerNorm affine-parameter gradient partials: fp32 [aptp_groupnorm_nchunk(rows), C, 2] = (sum dy, sum dy*xhat). */
+typedef struct {
+  const void* x; int64_t ldx;
+  const void* dy; int64_t lddy;
+  int32_t rows, C;
+  float eps;
+  float* partial;
+} AptpLayerNormPgradParams;
+int aptp_layernorm_pgrad(const AptpLayerNormPgradParams* p, aptp_stream_t stream);
 
 /* Attention backward: dq, dk, dv from q, k, v, o, dout and the forward's lse; delta is fp32 scratch [B, heads, Lq].
  * Same strided [B, L, heads, 64] layout convention as aptp_attention. */

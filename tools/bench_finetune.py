@@ -1,0 +1,69 @@
+"""BASELINE configs[4]: expert fine-tune step (teacher dense fwd + pruned student fwd/bwd incl. weight gradients + AdamW) at
+SD-2.1 size, one expert per GPU (rank r fine-tunes expert r: keep ratio 0.4..0.75, 0-4 depth gates off).
+Experts never communicate (scripts/aptp/finetune.py:27-28), so N GPUs = N independent processes; this tool runs ONE expert
+(--expert k) on cuda:0 and prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffusion_pruning_amd.train_step import FineTunerStep, synthetic_batch  # noqa: E402
+from diffusion_pruning_amd.unet import UNet2DConditionModelGated, UNet2DConditionModelPruned  # noqa: E402
+
+
+def expert_mask(structure, expert: int, device):
+    g = torch.Generator().manual_seed(1000 + expert)
+    keep = 0.4 + 0.05 * expert
+    width = []
+    for sub in structure["width"]:
+        for w in sub:
+            m = torch.zeros(1, w)
+            m[0, torch.randperm(w, generator=g)[:max(1, int(keep * w))]] = 0.9
+            width.append(m.to(device))
+    nd = sum(d for sub in structure["depth"] for d in sub)
+    depth = [torch.full((1,), 0.9, device=device) for _ in range(nd)]
+    for i in torch.randperm(nd, generator=g)[:expert % 5].tolist():
+        depth[i] = torch.zeros(1, device=device)
+    return {"width": width, "depth": depth}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--expert", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    teacher = UNet2DConditionModelGated().init_synthetic(seed=0)
+    student = UNet2DConditionModelPruned()
+    student.load_state_dict(teacher.state_dict())
+    teacher.to(dev).freeze()
+    st = teacher.get_structure()
+    teacher.set_structure({"width": [torch.ones(1, w, device=dev) for sub in st["width"] for w in sub],
+                           "depth": [torch.ones(1, device=dev) for sub in st["depth"] for d in sub if d == 1]})
+    student.to(dev)
+    student.prune(expert_mask(st, args.expert, dev))
+    step = FineTunerStep(student, teacher)
+    opt = torch.optim.AdamW([p for p in student.parameters() if p.requires_grad], lr=1e-5)
+    batch = synthetic_batch(args.batch, 64, dev)
+    for _ in range(args.warmup):
+        out = step.train_step(opt, batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step.train_step(opt, batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"metric": "expert-finetune-steps/s (SD-2.1 pruned expert, 64x64 latents, teacher fwd + student fwd/bwd/wgrad + AdamW)",
+                      "value": round(1.0 / dt, 3), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 1), "expert": args.expert,
+                      "batch": args.batch, "loss": float(out["loss"].detach()),
+                      "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "mode": "eager"}))
+
+
+if __name__ == "__main__":
+    main()

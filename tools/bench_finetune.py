@@ -1,7 +1,8 @@
 """BASELINE configs[4]: expert fine-tune step (teacher dense fwd + pruned student fwd/bwd incl. weight gradients + AdamW) at
 SD-2.1 size, one expert per GPU (rank r fine-tunes expert r: keep ratio 0.4..0.75, 0-4 depth gates off).
 Experts never communicate (scripts/aptp/finetune.py:27-28), so N GPUs = N independent processes; this tool runs ONE expert
-(--expert k) on cuda:0 and prints one JSON line."""
+(--expert k) on cuda:0 and prints one JSON line; under `python -m torch.distributed.run --nproc-per-node 8` every rank takes
+expert = RANK on cuda:LOCAL_RANK and prints its own line."""
 import argparse
 import json
 import os
@@ -38,7 +39,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    # under torchrun: one expert per GPU (rank r -> expert r on cuda:LOCAL_RANK); the processes never communicate
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" in os.environ:
+        args.expert = int(os.environ["RANK"])
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
     teacher = UNet2DConditionModelGated().init_synthetic(seed=0)
     student = UNet2DConditionModelPruned()
     student.load_state_dict(teacher.state_dict())

@@ -18,8 +18,34 @@ struct GnK {
   int B, HW, C, G, cg, CO;   // CO = ceil(C/8) octets per row
   const float* gamma; const float* beta; float eps; int silu;
   float* ws; int nchunk;
+  float* fin;                // finalised [B, G, 2] (mean, rstd), written by gn_finalize_kernel
   int TPR, RPAR;             // threads per row (= min(CO,256)), rows processed in parallel (256/TPR)
 };
+
+// stage 1.5: one workgroup per sample folds the nchunk partials ONCE (fixed order => deterministic).  Without it every
+// apply workgroup re-read all partials (32 KB each): more bytes than the activation tile it normalises.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnK p) {
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int g = tid >> 3, sub = tid & 7;
+  float a = 0.f, a2 = 0.f;
+  if (g < p.G) {
+    const float* w = p.ws + ((int64_t)b * p.nchunk * p.G + g) * 2;
+    for (int c = sub; c < p.nchunk; c += 8) { a += w[(int64_t)c * p.G * 2]; a2 += w[(int64_t)c * p.G * 2 + 1]; }
+  }
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off);
+    a2 += __shfl_xor(a2, off);
+  }
+  if (g < p.G && sub == 0) {
+    const float inv = 1.0f / ((float)p.cg * (float)p.HW);
+    const float mean = a * inv;
+    float var = a2 * inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    p.fin[((int64_t)b * p.G + g) * 2] = mean;
+    p.fin[((int64_t)b * p.G + g) * 2 + 1] = rsqrtf(var + p.eps);
+  }
+}
 
 template <int NP>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
@@ -139,27 +165,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
     }
   };
   load_rows(r0 + rl);
-  {
-    // fold the stage-1 partials: 8 threads per group, fixed order => deterministic
-    const int g = tid >> 3, sub = tid & 7;
-    float a = 0.f, a2 = 0.f;
-    if (g < p.G) {
-      const float* w = p.ws + ((int64_t)b * p.nchunk * p.G + g) * 2;
-      for (int c = sub; c < p.nchunk; c += 8) { a += w[(int64_t)c * p.G * 2]; a2 += w[(int64_t)c * p.G * 2 + 1]; }
-    }
-#pragma unroll
-    for (int off = 4; off >= 1; off >>= 1) {
-      a += __shfl_xor(a, off);
-      a2 += __shfl_xor(a2, off);
-    }
-    if (g < p.G && sub == 0) {
-      const float inv = 1.0f / ((float)p.cg * (float)p.HW);
-      const float mean = a * inv;
-      float var = a2 * inv - mean * mean;
-      var = var < 0.f ? 0.f : var;
-      mean_s[g] = mean;
-      rstd_s[g] = rsqrtf(var + p.eps);
-    }
+  if (tid < p.G) {
+    mean_s[tid] = p.fin[((int64_t)b * p.G + tid) * 2];
+    rstd_s[tid] = p.fin[((int64_t)b * p.G + tid) * 2 + 1];
   }
   __syncthreads();
   if (!active) return;
@@ -288,7 +296,8 @@ extern "C" int aptp_groupnorm_nchunk(int HW) {
 
 extern "C" int64_t aptp_groupnorm_workspace_bytes(const AptpGroupNormParams* p) {
   if (!p) return 0;
-  return (int64_t)p->B * aptp_groupnorm_nchunk(p->HW) * p->groups * 2 * (int64_t)sizeof(float);
+  // [B, nchunk, G, 2] partials followed by [B, G, 2] finalised (mean, rstd)
+  return (int64_t)p->B * (aptp_groupnorm_nchunk(p->HW) + 1) * p->groups * 2 * (int64_t)sizeof(float);
 }
 
 extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream) {
@@ -304,19 +313,22 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   k.B = p->B; k.HW = p->HW; k.C = p->C; k.G = p->groups; k.cg = p->C / p->groups; k.CO = CO;
   k.gamma = p->gamma; k.beta = p->beta; k.eps = p->eps; k.silu = p->silu;
   k.ws = (float*)p->workspace; k.nchunk = aptp_groupnorm_nchunk(p->HW);
+  k.fin = k.ws + (int64_t)p->B * k.nchunk * p->groups * 2;
   k.TPR = CO < 256 ? CO : 256;
   k.RPAR = 256 / k.TPR;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid1(k.nchunk, p->B);
   int nchunk2 = p->HW / 16;   // >= 16 rows per apply workgroup, up to 8 resident workgroups per CU
   if (nchunk2 < 1) nchunk2 = 1;
-  if (nchunk2 > 512) nchunk2 = 512;
+  if (nchunk2 > 256) nchunk2 = 256;
   dim3 grid2(nchunk2, p->B);
   if (CO <= 256) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(256), 0, s, k);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<2>, grid1, dim3(256), 0, s, k);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(256), 0, s, k);
   }
   APTP_LAUNCH_CHECK();

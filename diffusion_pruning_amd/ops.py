@@ -279,7 +279,13 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
     p.B, p.HW, p.C, p.groups = B, H * W, C, groups
     p.gamma, p.beta, p.eps, p.silu = gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
     if keep_stats:
-        ws = torch.empty(B, lib.aptp_groupnorm_nchunk(H * W), groups, 2, dtype=torch.float32, device=x.device)
+        # [B, nchunk + 1, G, 2]: the partials the backward needs, plus the finalised (mean, rstd) slot the kernels append
+        nch = lib.aptp_groupnorm_nchunk(H * W)
+        ws_full = torch.empty(B * (nch + 1) * groups * 2, dtype=torch.float32, device=x.device)
+        ws = ws_full[:B * nch * groups * 2].view(B, nch, groups, 2)
+        p.workspace = ws_full.data_ptr()
+        _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
+        return out, ws
     else:
         ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
     p.workspace = ws.data_ptr()

@@ -107,7 +107,8 @@ int aptp_conv_gemm_suggest_split_k(const AptpConvGemmParams* p);
  * (C/groups)*HW elements per (sample, group), biased variance, fp32 accumulation.
  * C need not be a multiple of 8 (compacted channel counts such as 17 groups x 10): rows are processed in 8-channel
  * octets, ld >= roundup8(C), and channels [C, roundup8(C)) of y are written as exact zeros.
- * workspace: fp32 [B, nchunk, groups, 2] with nchunk = aptp_groupnorm_nchunk(HW).
+ * workspace: aptp_groupnorm_workspace_bytes() = fp32 [B, nchunk, groups, 2] (sum, sumsq) partials, nchunk =
+ * aptp_groupnorm_nchunk(HW), followed by the finalised [B, groups, 2] (mean, rstd).
  */
 typedef struct {
   const void* x; int64_t ldx;   /* bf16 [B*HW, >=C] */

@@ -328,11 +328,15 @@ __device__ uint4 g_zero_page[512];
 // cin_pad/64 K-steps) and otherwise advanced by 128 B per K-step; PMC counters showed the previous per-step
 // recomputation (~115 VALU instructions per K-step per wave) made the loop VALU-issue-bound at 24 % MFMA utilisation.
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KParams p) {
+  constexpr int NW = WM * WN;                 // waves per workgroup: 4 (256 threads) or 8 (512 threads)
+  constexpr int NT = NW * 64;
+  constexpr int RPP = NT / 8;                 // tile rows covered by one LDS-DMA pass of the whole workgroup
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MF = WTM / 16, NF = WTN / 16;
-  constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+  constexpr int A_PASS = (BM + RPP - 1) / RPP, B_PASS = (BN + RPP - 1) / RPP;
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "tile shape");
 
   __shared__ __attribute__((aligned(16))) __bf16 smem[STAGES * (BM + BN) * BK];
   __bf16* As = smem;
@@ -356,8 +360,8 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
   int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS];
 #pragma unroll
   for (int i = 0; i < A_PASS; ++i) {
-    const int m = m0 + rowbase + 32 * i;
-    if (m < p.M) {
+    const int m = m0 + rowbase + RPP * i;
+    if (m < p.M && rowbase + RPP * i < BM) {
       const int b = m / p.HW, rem = m - b * p.HW;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
       a_iy0[i] = oy * p.stride - p.pad;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
   const char* b_ptr[B_PASS];
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) {
-    int n = n0 + rowbase + 32 * i;
+    int n = n0 + rowbase + RPP * i;
     n = n < p.N ? n : p.N - 1;            // columns past N accumulate garbage that is never stored
     b_ptr[i] = reinterpret_cast<const char*>(p.w) + ((int64_t)n * p.Ktot + (int64_t)kt_begin * BK + schunk * 8) * 2;
   }
@@ -402,15 +406,19 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
     const bool last_cc = l_cc == p.ncc - 1;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      const char* src = (last_cc && tail_bad) ? zpage : a_ptr[i];
-      __bf16* dst = As + (buf * BM + wave * 8 + 32 * i) * BK;      // wave-uniform; lane l lands at dst + l*16 B
-      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+      if (wave * 8 + RPP * i < BM) {                               // wave-uniform: the last pass may be partial
+        const char* src = (last_cc && tail_bad) ? zpage : a_ptr[i];
+        __bf16* dst = As + (buf * BM + wave * 8 + RPP * i) * BK;   // wave-uniform; lane l lands at dst + l*16 B
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+      }
       a_ptr[i] += BK * 2;
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      __bf16* dst = Bs + (buf * BN + wave * 8 + 32 * i) * BK;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)b_ptr[i], (lds_ptr)dst, 16, 0, 0);
+      if (wave * 8 + RPP * i < BN) {
+        __bf16* dst = Bs + (buf * BN + wave * 8 + RPP * i) * BK;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)b_ptr[i], (lds_ptr)dst, 16, 0, 0);
+      }
       b_ptr[i] += BK * 2;
     }
     if (++l_cc == p.ncc) {               // next tap (wave-uniform branch)
@@ -464,6 +472,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KParams p) {
       }
     }
   } else {
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "the counted-vmcnt ring needs every wave to issue the same number of DMAs");
     constexpr int NLD = A_PASS + B_PASS;     // LDS-DMA instructions per thread per tile
     if (kt_begin < kt_end) {
       issue_tile(0);
@@ -566,8 +575,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
 struct TileCfg { int bm, bn; };
 const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},
                           {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},    // 7..12: LDS-DMA, 2 stages
-                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64}};   // 13..18: LDS-DMA, 3 stages
-constexpr int kNumTiles = 19;
+                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},    // 13..18: LDS-DMA, 3 stages
+                          {128, 160}, {256, 160}, {128, 128}, {256, 128}};                      // 19..22: LDS-DMA, 8 waves
+constexpr int kNumTiles = 23;
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
   if (p->tile != APTP_TILE_AUTO) return p->tile;
@@ -647,6 +657,14 @@ void launch_tile_dma(const KParams& k, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, 2, STAGES>), grid, dim3(256), 0, s, k);
 }
 
+// 8-wave workgroups (512 threads, wave grid WM x WN): one weight tile shared by twice the rows
+template <int BM, int BN, int WM, int WN>
+void launch_tile_dma8(const KParams& k, hipStream_t s) {
+  const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
+  dim3 grid(tiles, k.split_k, 1);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, 2>), grid, dim3(512), 0, s, k);
+}
+
 }  // namespace
 
 extern "C" int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p) {
@@ -704,6 +722,10 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_DMA3_64x160: launch_tile_dma<64, 160, 3>(k, s); break;
     case APTP_TILE_DMA3_128x64: launch_tile_dma<128, 64, 3>(k, s); break;
     case APTP_TILE_DMA3_64x64: launch_tile_dma<64, 64, 3>(k, s); break;
+    case APTP_TILE_DMA8_128x160: launch_tile_dma8<128, 160, 4, 2>(k, s); break;
+    case APTP_TILE_DMA8_256x160: launch_tile_dma8<256, 160, 4, 2>(k, s); break;
+    case APTP_TILE_DMA8_128x128: launch_tile_dma8<128, 128, 2, 4>(k, s); break;
+    case APTP_TILE_DMA8_256x128: launch_tile_dma8<256, 128, 4, 2>(k, s); break;
     default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
   }
   APTP_LAUNCH_CHECK();

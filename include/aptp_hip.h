@@ -92,7 +92,9 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        APTP_TILE_DMA_128x64 = 11, APTP_TILE_DMA_64x64 = 12,
        /* LDS-DMA with a 3-deep ring (DMA two K-steps ahead, counted vmcnt + raw barrier) */
        APTP_TILE_DMA3_128x128 = 13, APTP_TILE_DMA3_128x160 = 14, APTP_TILE_DMA3_64x128 = 15, APTP_TILE_DMA3_64x160 = 16,
-       APTP_TILE_DMA3_128x64 = 17, APTP_TILE_DMA3_64x64 = 18 };
+       APTP_TILE_DMA3_128x64 = 17, APTP_TILE_DMA3_64x64 = 18,
+       /* LDS-DMA, 8-wave (512-thread) workgroups: one weight tile shared by twice the rows */
+       APTP_TILE_DMA8_128x160 = 19, APTP_TILE_DMA8_256x160 = 20, APTP_TILE_DMA8_128x128 = 21, APTP_TILE_DMA8_256x128 = 22 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

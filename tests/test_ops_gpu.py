@@ -75,6 +75,16 @@ CONV_CASES = [
     (4, 64, 64, 320, 320, 3, 1, 0, 16, 1),
     (4, 64, 64, 320, 320, 3, 1, 0, 14, 1),
     (4, 32, 32, 1280, 640, 3, 1, 0, 14, 3),
+    # 8-wave LDS-DMA workgroups (tiles 19..22)
+    (2, 32, 32, 160, 320, 3, 1, 0, 19, 1),
+    (4, 64, 64, 160, 320, 3, 1, 0, 19, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 20, 1),
+    (2, 16, 16, 128, 128, 3, 2, 0, 21, 1),
+    (2, 8, 8, 128, 128, 3, 1, 1, 22, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 19, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 21, 2),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 22, 4),
+    (2, 16, 16, 192, 128, 1, 1, 0, 20, 1),
 ]
 
 
@@ -148,7 +158,7 @@ def test_conv_full_epilogue(ops, cuda, split_k):
     assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), ref) <= REL_L2_TOL
 
 
-@pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6)])
+@pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6), (1, 21), (2, 22), (1, 9), (1, 15)])
 def test_linear_geglu(ops, cuda, split_k, tile):
     g = torch.Generator().manual_seed(13)
     B, L, C, inner = 2, 96, 64, 256

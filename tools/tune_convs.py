@@ -83,7 +83,7 @@ def main():
         M, nK = p0.B * p0.Hout * p0.Wout, p0.KH * p0.KW * (p0.cin_pad // 64)
         base = clone_params(p0)
         t_base = time_launch(lib, base)
-        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18] if p0.act == ACT_GEGLU else list(range(1, 19))
+        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18, 21, 22] if p0.act == ACT_GEGLU else list(range(1, 23))
         splits = [1, 2, 3, 4, 6, 8, 12, 16, 24]
         if args.quick:
             splits = [1, 2, 4, 8]

@@ -49,7 +49,7 @@ class GroupNormParams(Structure):
         ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("groups", c_int32),
         ("gamma", c_void_p), ("beta", c_void_p),
         ("eps", c_float), ("silu", c_int32),
-        ("workspace", c_void_p),
+        ("workspace", c_void_p), ("variant", c_int32),
     ]
 
 

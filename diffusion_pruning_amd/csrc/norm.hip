@@ -225,6 +225,159 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Single-launch GroupNorm: one workgroup OWNS gpb whole groups of one sample (a [HW, gpb*cg] column slab; gpb*cg is a
+// multiple of 8, so the slab is made of 16-byte chunks) and keeps the slab in registers (U chunks per thread), so the
+// statistics never leave the workgroup and x is read once: load -> reduce -> normalise -> store.  No inter-workgroup
+// hand-off, deterministic.  Used where the slab fits (HW * gpb*cg/8 <= U * NT chunks); three dependent launches cost
+// 13-30 us on those maps, this one 6-12.
+// ------------------------------------------------------------------------------------------------------------
+struct GnG {
+  const __bf16* x; int64_t ldx; __bf16* y; int64_t ldy;
+  int B, HW, C, G, cg;
+  const float* gamma; const float* beta; float eps; int silu;
+  int gpb;        // groups per workgroup (1, 2, 4 or 8)
+  int TPR, RPAR;  // chunks per slab row (= gpb*cg/8 <= 32), rows in parallel (NT / TPR)
+  int R256;       // rows folded per LDS round (256 / TPR)
+};
+
+template <int U, int NT>
+__global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
+  __shared__ float red[2][2048];
+  __shared__ float chs[2][256];
+  __shared__ float mean_s[8], rstd_s[8];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, g0 = blockIdx.x * p.gpb;
+  const int ng = (p.G - g0 < p.gpb) ? p.G - g0 : p.gpb;
+  const int c0 = g0 * p.cg;                         // multiple of 8 by construction
+  const int c1 = c0 + ng * p.cg;                    // <= C
+  const int w16 = ((c1 + 7) / 8) - c0 / 8;          // chunks of this slab (the last one may hold zero padding)
+  const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
+  const bool active = rl < p.RPAR && ot < w16;
+  __bf16* yb = p.y + ((int64_t)b * p.HW) * p.ldy + c0 + ot * 8;
+  // the slab: every load of the thread is issued before the first use.  Buffer loads: rows past the sample (and the
+  // lanes without a chunk) read as zero from the out-of-range offset, so no select doubles the registers.
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(p.x + ((int64_t)b * p.HW) * p.ldx), 0, (int)(((int64_t)(p.HW - 1) * p.ldx + ((p.C + 7) / 8) * 8) * 2), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned col_b = (unsigned)(c0 + ot * 8) * 2u, ld_b = (unsigned)p.ldx * 2u;
+  u32x4 q[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int rr = rl + u * p.RPAR;
+    q[u] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (active && rr < p.HW) ? (unsigned)rr * ld_b + col_b : OOB, 0, 0);
+  }
+  {
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // opaque touch: the chunk is unpacked HERE and again in the normalise loop, so the slab stays packed in between
+      // (4 registers per chunk instead of 8 unpacked floats held across the reduction)
+      asm volatile("" : "+v"(q[u].x), "+v"(q[u].y), "+v"(q[u].z), "+v"(q[u].w));
+      float f[8];
+      union { u32x4 v; uint4 s4; } cv; cv.v = q[u];
+      unpack_bf16x8(cv.s4, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+    }
+    // per-channel partials of the rows-in-parallel -> LDS, R256 row slots per round (fixed order => deterministic)
+    const int CP = p.TPR * 8;
+    const int rounds = (p.RPAR + p.R256 - 1) / p.R256;
+    const int myround = rl / p.R256, slot = rl - myround * p.R256;
+    for (int rd = 0; rd < rounds; ++rd) {
+      if (rl < p.RPAR && myround == rd) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int i = slot * CP + ot * 8 + e;
+          if (rd == 0) { red[0][i] = s[e]; red[1][i] = ss[e]; }
+          else { red[0][i] += s[e]; red[1][i] += ss[e]; }
+        }
+      }
+      __syncthreads();
+    }
+    // stage 1: thread c folds the row slots of slab channel c (conflict-free LDS walk)
+    const int nslot = p.RPAR < p.R256 ? p.RPAR : p.R256;
+    if (tid < CP) {
+      float a = 0.f, a2 = 0.f;
+      for (int rr = 0; rr < nslot; ++rr) { a += red[0][rr * CP + tid]; a2 += red[1][rr * CP + tid]; }
+      chs[0][tid] = a;
+      chs[1][tid] = a2;
+    }
+    __syncthreads();
+    // stage 2: 32 lanes per owned group fold its cg channels
+    const int lg = tid >> 5, l32 = tid & 31;
+    float a = 0.f, a2 = 0.f;
+    if (lg < ng) {
+      for (int i = l32; i < p.cg; i += 32) {
+        a += chs[0][lg * p.cg + i];
+        a2 += chs[1][lg * p.cg + i];
+      }
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+      a += __shfl_xor(a, off);
+      a2 += __shfl_xor(a2, off);
+    }
+    if (lg < ng && l32 == 0) {
+      const float inv = 1.0f / ((float)p.cg * (float)p.HW);
+      const float mean = a * inv;
+      float var = a2 * inv - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      mean_s[lg] = mean;
+      rstd_s[lg] = rsqrtf(var + p.eps);
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8];
+  unsigned valid = 0u;
+  {
+    int lg = (ot * 8) / p.cg, rem = ot * 8 - lg * p.cg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + ot * 8 + e;
+      if (c < c1) {
+        const float k = rstd_s[lg] * p.gamma[c];
+        sc[e] = k;
+        sh[e] = p.beta[c] - mean_s[lg] * k;
+        valid |= 1u << e;
+      } else {
+        sc[e] = 0.f; sh[e] = 0.f;
+      }
+      if (++rem == p.cg) { rem = 0; ++lg; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int rr = rl + u * p.RPAR;
+    asm volatile("" : "+v"(q[u].x), "+v"(q[u].y), "+v"(q[u].z), "+v"(q[u].w));
+    if (rr < p.HW) {
+      float f[8];
+      union { u32x4 v; uint4 s4; } cv; cv.v = q[u];
+      unpack_bf16x8(cv.s4, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = f[e] * sc[e] + sh[e];
+        if (p.silu) v = silu_f(v);
+        f[e] = ((valid >> e) & 1u) ? v : 0.f;   // padding channels of the last chunk: exact zero
+      }
+      *reinterpret_cast<uint4*>(yb + (int64_t)rr * p.ldy) = pack_bf16x8(f);
+    }
+  }
+}
+
+template <int NT>
+bool launch_group(const GnG& q, int rows, dim3 grid, hipStream_t s) {
+  if (rows <= 4) hipLaunchKernelGGL((gn_group_kernel<4, NT>), grid, dim3(NT), 0, s, q);
+  else if (rows <= 8) hipLaunchKernelGGL((gn_group_kernel<8, NT>), grid, dim3(NT), 0, s, q);
+  else if (rows <= 16) hipLaunchKernelGGL((gn_group_kernel<16, NT>), grid, dim3(NT), 0, s, q);
+  else if (rows <= 24 && NT == 256) hipLaunchKernelGGL((gn_group_kernel<24, 256>), grid, dim3(256), 0, s, q);
+  else return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, lane handles octets lane, lane+64, ...; exact two-pass statistics in registers.
 // ------------------------------------------------------------------------------------------------------------
 struct LnK {
@@ -287,6 +440,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnK p) {
 
 }  // namespace
 
+#ifndef APTP_GN_GROUP_MAX_HW
+#define APTP_GN_GROUP_MAX_HW 256
+#endif
+
 extern "C" int aptp_groupnorm_nchunk(int HW) {
   int n = HW / 16;   // >= 16 rows per stage-1 workgroup
   if (n < 1) n = 1;
@@ -317,6 +474,38 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   k.TPR = CO < 256 ? CO : 256;
   k.RPAR = 256 / k.TPR;
   hipStream_t s = (hipStream_t)stream;
+  APTP_CHECK(p->variant >= 0 && p->variant <= 2, "groupnorm: variant %d", p->variant);
+  // group-owner single launch: gpb = fewest groups whose channels fill whole 16-byte chunks
+  int gpb = 1;
+  while ((gpb * k.cg) % 8 != 0) gpb *= 2;   // cg * 8 is always a multiple of 8, so gpb <= 8
+  const int tpr = gpb * k.cg / 8;
+  if (p->variant != 1 && tpr <= 32) {
+    GnG q;
+    q.x = k.x; q.ldx = k.ldx; q.y = k.y; q.ldy = k.ldy; q.B = k.B; q.HW = k.HW; q.C = k.C; q.G = k.G; q.cg = k.cg;
+    q.gamma = k.gamma; q.beta = k.beta; q.eps = k.eps; q.silu = k.silu;
+    q.gpb = gpb; q.TPR = tpr; q.R256 = 256 / tpr;
+    const dim3 grid((k.G + gpb - 1) / gpb, k.B);
+    bool done = false;
+    q.RPAR = 256 / tpr;
+    int rows = (k.HW + q.RPAR - 1) / q.RPAR;
+    // variant 0: only the small maps.  One workgroup streams its whole slab through one CU, and a CU's outstanding-miss
+    // budget makes that slower than three chip-wide launches from HW = 1024 up (tools/bench_gn.py on MI355X: 6-12 us vs
+    // 11-30 us at HW <= 256; 14-32 vs 13-24 at HW = 1024; 40-50 vs 21-35 at HW = 4096).
+    if (p->variant == 2 || k.HW <= APTP_GN_GROUP_MAX_HW) {
+      if (rows <= 24) {
+        done = launch_group<256>(q, rows, grid, s);
+      } else {
+        q.RPAR = 1024 / tpr;
+        rows = (k.HW + q.RPAR - 1) / q.RPAR;
+        if (rows <= 16) done = launch_group<1024>(q, rows, grid, s);
+      }
+    }
+    if (done) {
+      APTP_LAUNCH_CHECK();
+      return APTP_OK;
+    }
+  }
+  APTP_CHECK(p->variant != 2, "groupnorm: variant 2 does not fit (HW %d, cg %d: slab too large for one workgroup's registers)", p->HW, k.cg);
   dim3 grid1(k.nchunk, p->B);
   int nchunk2 = p->HW / 16;   // >= 16 rows per apply workgroup, up to 8 resident workgroups per CU
   if (nchunk2 < 1) nchunk2 = 1;

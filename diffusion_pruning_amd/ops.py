@@ -263,9 +263,10 @@ def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
-              C: Optional[int] = None, out: Optional[torch.Tensor] = None, keep_stats: bool = False):
+              C: Optional[int] = None, out: Optional[torch.Tensor] = None, keep_stats: bool = False, variant: int = 0):
     """GroupNorm(+SiLU) of a [B,H,W,Cp] tensor over its first C real channels (Cp = roundup8(C)).
-    keep_stats: also return the fp32 [B, nchunk, groups, 2] statistics partials (needed by groupnorm_bwd)."""
+    keep_stats: also return the fp32 [B, nchunk, groups, 2] statistics partials (needed by groupnorm_bwd; forces the
+    three-launch form).  variant: see AptpGroupNormParams in include/aptp_hip.h."""
     lib = _lib.load()
     _check_act(x, "groupnorm x")
     B, H, W, Cp = x.shape
@@ -284,10 +285,12 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
         ws_full = torch.empty(B * (nch + 1) * groups * 2, dtype=torch.float32, device=x.device)
         ws = ws_full[:B * nch * groups * 2].view(B, nch, groups, 2)
         p.workspace = ws_full.data_ptr()
+        p.variant = 1
         _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
         return out, ws
     else:
         ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
+    p.variant = variant
     p.workspace = ws.data_ptr()
     _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
     return (out, ws) if keep_stats else out

@@ -120,6 +120,9 @@ typedef struct {
   float eps;
   int32_t silu;
   void* workspace;
+  /* 0 = auto; 1 = three launches (stats, finalise, apply): the only form that fills the workspace partials
+   * aptp_groupnorm_bwd consumes; 2 = one launch, each workgroup owning whole groups of one sample (small maps). */
+  int32_t variant;
 } AptpGroupNormParams;
 
 int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream);

@@ -208,11 +208,21 @@ GN_CASES = [
     (2, 8, 8, 1920, 32, True, 1e-5),
     (3, 4, 4, 170, 17, True, 1e-5),      # compacted: 17 live groups of 10, padded to 176 columns
     (2, 8, 8, 960, 32, True, 1e-5),
+    (2, 16, 16, 1280, 32, True, 1e-5),   # level-16 map: 16 slab rows per thread
+    (1, 16, 16, 2560, 32, True, 1e-5),
+    (2, 16, 16, 85, 17, True, 1e-5),     # 17 live groups of 5: 8 groups per workgroup, ragged last one, padded to 88
+    (2, 16, 16, 340, 17, False, 1e-5),   # groups of 20: 2 per workgroup, ragged last one
+    (1, 16, 16, 2048, 8, True, 1e-5),    # groups of 256 = 32 chunks per slab row
+    (1, 32, 32, 640, 32, True, 1e-5),
+    (1, 64, 64, 320, 32, True, 1e-5),
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", GN_CASES)
-def test_groupnorm(ops, cuda, case):
+def test_groupnorm(ops, cuda, case, variant):
+    """variant 1 = three launches (the form the backward consumes), 2 = one launch with group-owning workgroups,
+    0 = the library's choice; all against F.group_norm in fp32"""
     B, H, W, C, G, silu, eps = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = (_rand((B, C, H, W), g) * 2.0 + 0.7).bfloat16()
@@ -221,7 +231,12 @@ def test_groupnorm(ops, cuda, case):
     Cp = ops.round_up(C, 8)
     xin = torch.full((B, H, W, Cp), 0.0, dtype=torch.bfloat16)
     xin[..., :C] = nhwc(x)
-    y = ops.groupnorm(xin.to(cuda), gamma.to(cuda), beta.to(cuda), G, eps, silu, C=C)
+    try:
+        y = ops.groupnorm(xin.to(cuda), gamma.to(cuda), beta.to(cuda), G, eps, silu, C=C, variant=variant)
+    except Exception as e:
+        if variant == 2 and "does not fit" in str(e):
+            pytest.skip("slab too large for the single-launch form")
+        raise
     ref = F.group_norm(x.float(), G, gamma, beta, eps)
     if silu:
         ref = F.silu(ref)
@@ -229,6 +244,35 @@ def test_groupnorm(ops, cuda, case):
     assert rel_l2(got[..., :C].permute(0, 3, 1, 2), ref) <= REL_L2_TOL
     if Cp > C:
         assert float(got[..., C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_groupnorm_strided_view_and_determinism(ops, cuda, variant):
+    """input = channel slice of a wider (concat) buffer, output into a slice too; two runs are bit-identical"""
+    B, H, W, C, G = 2, 16, 16, 640, 32
+    g = torch.Generator().manual_seed(11)
+    wide = (_rand((B, H, W, C + 320), g) * 3 + 1).bfloat16().to(cuda)
+    x = wide[..., 320:]
+    gamma = (1.0 + 0.2 * _rand((C,), g)).to(cuda)
+    beta = (0.3 * _rand((C,), g)).to(cuda)
+    outw = torch.zeros(B, H, W, C + 64, dtype=torch.bfloat16, device=cuda)
+    y = ops.groupnorm(x, gamma, beta, G, 1e-5, True, out=outw[..., :C], variant=variant)
+    y2 = ops.groupnorm(x.contiguous(), gamma, beta, G, 1e-5, True, variant=variant)
+    assert torch.equal(y, y2)
+    assert float(outw[..., C:].abs().max()) == 0.0
+    ref = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), G, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    assert rel_l2(y.float().cpu(), ref.cpu()) <= REL_L2_TOL
+
+
+def test_groupnorm_variants_agree(ops, cuda):
+    """the single-launch and three-launch forms see the same statistics (different fold order only)"""
+    g = torch.Generator().manual_seed(12)
+    x = (_rand((4, 8, 8, 1280), g) * 2 - 0.3).bfloat16().to(cuda)
+    gamma = (1.0 + 0.2 * _rand((1280,), g)).to(cuda)
+    beta = (0.3 * _rand((1280,), g)).to(cuda)
+    a = ops.groupnorm(x, gamma, beta, 32, 1e-5, True, variant=1).float()
+    b = ops.groupnorm(x, gamma, beta, 32, 1e-5, True, variant=2).float()
+    assert float((a - b).abs().max()) <= 2 ** -6 * float(a.abs().max())
 
 
 def test_groupnorm_zero_group_gives_beta(ops, cuda):

@@ -11,6 +11,18 @@
 // The architecture-code gate, time-embedding bias, GEGLU, GroupNorm-beta correction, residual and depth lerp are
 // fused into the epilogue (see include/aptp_hip.h for the reference call sites each one replaces).
 #include "aptp_common.h"
+// In-kernel stamps (timing experiments only, -DAPTP_STAMPS): per-wave cycle totals of the K-loop segments
+// [0->1 DMA issue, 1->2 LDS reads + MFMAs, 2->3 waits + barrier], dumped by lane 0 of every wave into g_stamps.
+#ifdef APTP_STAMPS
+__device__ unsigned long long g_stamps[4096 * 4];
+#define APTP_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
+    if ((i) > 0) st_acc[(i) - 1] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define APTP_STAMP(i) do { } while (0)
+#endif
+#ifndef APTP_ABLATE
+#define APTP_ABLATE 0   // timing experiments only (tools/ablate_conv.sh): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no ds_read, 8 no barrier
+#endif
 
 namespace {
 
@@ -221,6 +233,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
     for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
+#if APTP_ABLATE & 4
+  bf16x8 abl_frag;
+  for (int e = 0; e < 8; ++e) abl_frag[e] = (__bf16)(float)(lane + e);
+  asm volatile("" : "+v"(abl_frag));
+#endif
   auto compute = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -327,7 +344,7 @@ __device__ uint4 g_zero_page[512];
 // Address generation is incremental: the per-row source pointer is recomputed only when the filter tap changes (every
 // cin_pad/64 K-steps) and otherwise advanced by 128 B per K-step; PMC counters showed the previous per-step
 // recomputation (~115 VALU instructions per K-step per wave) made the loop VALU-issue-bound at 24 % MFMA utilisation.
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KParams p) {
   constexpr int NW = WM * WN;                 // waves per workgroup: 4 (256 threads) or 8 (512 threads)
   constexpr int NT = NW * 64;
@@ -402,6 +419,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
+#if APTP_ABLATE & 1
+  bool abl_first = true;
+#endif
   auto issue_tile = [&](int buf) {
     const bool last_cc = l_cc == p.ncc - 1;
 #pragma unroll
@@ -409,6 +429,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
       if (wave * 8 + RPP * i < BM) {                               // wave-uniform: the last pass may be partial
         const char* src = (last_cc && tail_bad) ? zpage : a_ptr[i];
         __bf16* dst = As + (buf * BM + wave * 8 + RPP * i) * BK;   // wave-uniform; lane l lands at dst + l*16 B
+#if APTP_ABLATE & 1
+        if (abl_first)
+#endif
         __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
       }
       a_ptr[i] += BK * 2;
@@ -417,6 +440,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     for (int i = 0; i < B_PASS; ++i) {
       if (wave * 8 + RPP * i < BN) {
         __bf16* dst = Bs + (buf * BN + wave * 8 + RPP * i) * BK;
+#if APTP_ABLATE & 1
+        if (abl_first)
+#endif
         __builtin_amdgcn_global_load_lds((gbl_ptr)b_ptr[i], (lds_ptr)dst, 16, 0, 0);
       }
       b_ptr[i] += BK * 2;
@@ -426,6 +452,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
       if (++l_kx == p.KW) { l_kx = 0; ++l_ky; }
       set_tap(0);
     }
+#if APTP_ABLATE & 1
+    abl_first = false;
+#endif
   };
 
   f32x4 acc[MF][NF];
@@ -434,7 +463,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
 #pragma unroll
     for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef APTP_STAMPS
+  unsigned long long st_acc[3] = {0, 0, 0}, st_prev = 0;
+  const unsigned long long st_begin = __builtin_readcyclecounter();
+#endif
   const int frow = lane & 15, fq = lane >> 4;
+#if APTP_ABLATE & 4
+  bf16x8 abl_frag;
+  for (int e = 0; e < 8; ++e) abl_frag[e] = (__bf16)(float)(lane + e);
+  asm volatile("" : "+v"(abl_frag));
+#endif
   auto compute = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -443,64 +481,188 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
       for (int i = 0; i < MF; ++i) {
         const int r = wm * WTM + i * 16 + frow;
         const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+#if APTP_ABLATE & 4
+        af[i] = abl_frag; (void)r; (void)sw;
+#else
         af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * BM + r) * BK + sw * 8);
+#endif
       }
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
         const int r = wn * WTN + j * 16 + frow;
         const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+#if APTP_ABLATE & 4
+        wf[j] = abl_frag; (void)r; (void)sw;
+#else
         wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * BN + r) * BK + sw * 8);
+#endif
       }
 #pragma unroll
       for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
+        for (int j = 0; j < NF; ++j) {
+#if APTP_ABLATE & 2
+          asm volatile("" :: "v"(wf[j]), "v"(af[i]));
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+#endif
+        }
     }
   };
 
+  if constexpr (PP) {
+    // Ping-pong schedule (8 waves = two groups of four; waves w and w+4 share a SIMD).  Every K-step is two slots
+    // separated by workgroup barriers: in slot L a wave issues its share of the LDS-DMA for tile k+D, in slot C it
+    // reads the fragments of tile k from LDS and runs the MFMAs.  Group 1 runs one slot behind group 0, so on every
+    // SIMD one wave drives the matrix pipe (and the LDS read port) while the other drives the load path.  In the
+    // lockstep loops the three engines take turns (in-kernel stamps, 128x160 tile: DMA issue 490-550, LDS reads + MFMA
+    // 470-525, waits 400-550 cycles per K-step).
+    //   RAW: a wave waits for its own DMA rows of tile k+1 at the end of C(k); group 0 reads tile k+1 two barriers
+    //        later, group 1 three.
+    //   WAR: tile k+D lands in the stage of tile k+D-S = k-2 (S = D+2), last read by group 1 in its C(k-2), which ends
+    //        one barrier before group 0's L(k) starts.  (S = D+1 would let group 0's DMA overwrite the stage group 1 is
+    //        still reading in the same slot.)
+    static_assert(NW == 8 && STAGES >= 3, "ping-pong needs 8 waves and a ring of >= 3 stages");
+    static_assert(BM % RPP == 0, "ring: the activation tile must be whole row passes");
+    constexpr int D = STAGES - 2;
+    constexpr int A_FULL = BM / RPP, B_FULL = BN / RPP;
+    constexpr int NLD_LO = A_FULL + B_FULL, NLD_HI = A_PASS + B_PASS;
+    static_assert(NLD_HI * (D - 1) <= 63, "vmcnt immediate");
+    const bool hi = (NLD_HI != NLD_LO) && (wave * 8 + RPP * (B_PASS - 1) < BN);   // wave-uniform
+    const int grp = wave >> 2;
+    const int n = kt_end - kt_begin;
+    if (n > 0) {
+      const int pre = n < D ? n : D;
+      for (int t = 0; t < pre; ++t) issue_tile(t);
+      if (pre == D) {
+        if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (grp == 1) {                       // stagger: group 1 starts one slot late
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      int cur = 0, nxt = D % STAGES;
+      for (int kt = 0; kt < n; ++kt) {
+        // ---- slot L(kt): the load path ----
+        APTP_STAMP(0);
+        const bool issue = kt + D < n;
+        if (issue) issue_tile(nxt);
+        APTP_STAMP(1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        // ---- slot C(kt): LDS reads + MFMAs ----
+        __builtin_amdgcn_s_setprio(1);
+        compute(cur);
+        __builtin_amdgcn_s_setprio(0);
+        APTP_STAMP(2);
+        asm volatile("" ::: "memory");
+#if !(APTP_ABLATE & 16)
+        if (issue) {
+          if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        APTP_STAMP(3);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+      }
+      if (grp == 0) {                       // group 0 pairs group 1's last barrier
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+  } else
   if constexpr (STAGES == 2) {
     if (kt_begin < kt_end) {
       issue_tile(0);
       __syncthreads();                       // (the compiler drains vmcnt(0) for the LDS-DMA before the barrier)
       int buf = 0;
       for (int kt = kt_begin; kt < kt_end; ++kt) {
+        APTP_STAMP(0);
         if (kt + 1 < kt_end) issue_tile(buf ^ 1);   // in flight during the MFMAs below
+        APTP_STAMP(1);
         compute(buf);
+        APTP_STAMP(2);
+#if !(APTP_ABLATE & 8)
         __syncthreads();
+#endif
+        APTP_STAMP(3);
         buf ^= 1;
       }
     }
   } else {
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "the counted-vmcnt ring needs every wave to issue the same number of DMAs");
-    constexpr int NLD = A_PASS + B_PASS;     // LDS-DMA instructions per thread per tile
-    if (kt_begin < kt_end) {
-      issue_tile(0);
-      if (kt_begin + 1 < kt_end) {
-        issue_tile(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // tile 0 landed, tile 1 still in flight
+    // STAGES-deep ring, D = STAGES-1 tiles of LDS-DMA in flight across the barriers (counted vmcnt, raw s_barrier): the
+    // operand round trip (~1-2k cycles) is several K-steps long at these tile sizes, so one tile ahead is not enough.
+    //   iteration kt: issue tile kt+D into stage (kt+D)%S == (kt-1)%S (last read before the previous barrier),
+    //                 compute stage kt%S, wait until tile kt+1 has landed (D-1 newer tiles stay in flight), barrier.
+    // Waves may issue different numbers of DMAs per tile (partial last row pass): each waits on its own count.
+    constexpr int D = STAGES - 1;
+    constexpr int A_FULL = BM / RPP, B_FULL = BN / RPP;            // passes every wave takes part in
+    constexpr int NLD_LO = A_FULL + B_FULL;
+    constexpr int NLD_HI = A_PASS + B_PASS;
+    static_assert(BM % RPP == 0, "ring: the activation tile must be whole row passes");
+    static_assert(NLD_HI * (D - 1) <= 63, "vmcnt immediate");
+    const bool hi = (NLD_HI != NLD_LO) && (wave * 8 + RPP * (B_PASS - 1) < BN);   // wave-uniform
+    const int n = kt_end - kt_begin;
+    if (n > 0) {
+      const int pre = n < D ? n : D;
+      for (int t = 0; t < pre; ++t) issue_tile(t);
+      if (pre == D) {   // tile 0 landed, D-1 tiles still in flight
+        if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      int cur = 0;
-      for (int kt = kt_begin; kt < kt_end; ++kt) {
-        int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
-        const bool issue = kt + 2 < kt_end;
-        if (issue) issue_tile(nxt2);           // stage (kt+2)%3 == (kt-1)%3: last read before the previous barrier
+      int cur = 0, nxt = D;          // stage of tile kt, stage of tile kt+D
+      for (int kt = 0; kt < n; ++kt) {
+        const bool issue = kt + D < n;
+        APTP_STAMP(0);
+        if (issue) issue_tile(nxt);
+        APTP_STAMP(1);
         compute(cur);
+        APTP_STAMP(2);
         asm volatile("" ::: "memory");
-        if (issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // tile kt+1 landed; kt+2 in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // this wave's LDS reads of `cur` are done
+        if (issue) {
+          if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tail: everything still in flight is needed soon
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS reads of `cur` are done
+#if !(APTP_ABLATE & 8)
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
-        cur = cur + 1 == 3 ? 0 : cur + 1;
+        APTP_STAMP(3);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
       }
     }
   }
 
+#ifdef APTP_STAMPS
+  if (lane == 0 && blockIdx.y == 0) {
+    const int slot = (blockIdx.x * NW + wave) & 4095;
+    g_stamps[slot * 4 + 0] = st_acc[0]; g_stamps[slot * 4 + 1] = st_acc[1]; g_stamps[slot * 4 + 2] = st_acc[2];
+    g_stamps[slot * 4 + 3] = __builtin_readcyclecounter() - st_begin;
+  }
+#endif
   if (p.split_k > 1) {
     float* ws = p.ws + (int64_t)kz * p.M * p.ws_ld;
 #pragma unroll
@@ -576,8 +738,12 @@ struct TileCfg { int bm, bn; };
 const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},
                           {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},    // 7..12: LDS-DMA, 2 stages
                           {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},    // 13..18: LDS-DMA, 3 stages
-                          {128, 160}, {256, 160}, {128, 128}, {256, 128}};                      // 19..22: LDS-DMA, 8 waves
-constexpr int kNumTiles = 23;
+                          {128, 160}, {256, 160}, {128, 128}, {256, 128},                       // 19..22: LDS-DMA, 8 waves
+                          {64, 160}, {64, 128}, {64, 64}, {128, 64}, {128, 128},                // 23..27: LDS-DMA, 4 stages
+                          {128, 160}, {128, 160}, {128, 128}, {128, 128}, {256, 128},           // 28..32: 8 waves, 3/4-stage ring
+                          {128, 160}, {128, 160}, {128, 128}, {128, 128}, {64, 160}, {64, 128}, // 33..38: 8 waves, ping-pong
+                          {64, 160}, {128, 64}};                                                // 39..40
+constexpr int kNumTiles = 41;
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
   if (p->tile != APTP_TILE_AUTO) return p->tile;
@@ -658,14 +824,28 @@ void launch_tile_dma(const KParams& k, hipStream_t s) {
 }
 
 // 8-wave workgroups (512 threads, wave grid WM x WN): one weight tile shared by twice the rows
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES = 2>
 void launch_tile_dma8(const KParams& k, hipStream_t s) {
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
   dim3 grid(tiles, k.split_k, 1);
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, 2>), grid, dim3(512), 0, s, k);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(512), 0, s, k);
+}
+
+// 8-wave ping-pong schedule (see the kernel): wave grid WM x WN, STAGES-deep ring
+template <int BM, int BN, int WM, int WN, int STAGES>
+void launch_tile_pp(const KParams& k, hipStream_t s) {
+  const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
+  dim3 grid(tiles, k.split_k, 1);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, true>), grid, dim3(512), 0, s, k);
 }
 
 }  // namespace
+
+#ifdef APTP_STAMPS
+extern "C" int aptp_debug_read_stamps(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p) {
   if (!p || p->split_k <= 1) return 0;
@@ -726,6 +906,24 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_DMA8_256x160: launch_tile_dma8<256, 160, 4, 2>(k, s); break;
     case APTP_TILE_DMA8_128x128: launch_tile_dma8<128, 128, 2, 4>(k, s); break;
     case APTP_TILE_DMA8_256x128: launch_tile_dma8<256, 128, 4, 2>(k, s); break;
+    case APTP_TILE_DMA4_64x160: launch_tile_dma<64, 160, 4>(k, s); break;
+    case APTP_TILE_DMA4_64x128: launch_tile_dma<64, 128, 4>(k, s); break;
+    case APTP_TILE_DMA4_64x64: launch_tile_dma<64, 64, 4>(k, s); break;
+    case APTP_TILE_DMA4_128x64: launch_tile_dma<128, 64, 4>(k, s); break;
+    case APTP_TILE_DMA4_128x128: launch_tile_dma<128, 128, 4>(k, s); break;
+    case APTP_TILE_DMA8R3_128x160: launch_tile_dma8<128, 160, 4, 2, 3>(k, s); break;
+    case APTP_TILE_DMA8R4_128x160: launch_tile_dma8<128, 160, 4, 2, 4>(k, s); break;
+    case APTP_TILE_DMA8R3_128x128: launch_tile_dma8<128, 128, 2, 4, 3>(k, s); break;
+    case APTP_TILE_DMA8R4_128x128: launch_tile_dma8<128, 128, 2, 4, 4>(k, s); break;
+    case APTP_TILE_DMA8R3_256x128: launch_tile_dma8<256, 128, 4, 2, 3>(k, s); break;
+    case APTP_TILE_PP3_128x160: launch_tile_pp<128, 160, 4, 2, 3>(k, s); break;
+    case APTP_TILE_PP4_128x160: launch_tile_pp<128, 160, 4, 2, 4>(k, s); break;
+    case APTP_TILE_PP3_128x128: launch_tile_pp<128, 128, 2, 4, 3>(k, s); break;
+    case APTP_TILE_PP4_128x128: launch_tile_pp<128, 128, 2, 4, 4>(k, s); break;
+    case APTP_TILE_PP4_64x160: launch_tile_pp<64, 160, 4, 2, 4>(k, s); break;
+    case APTP_TILE_PP4_64x128: launch_tile_pp<64, 128, 2, 4, 4>(k, s); break;
+    case APTP_TILE_PP5_64x160: launch_tile_pp<64, 160, 4, 2, 5>(k, s); break;
+    case APTP_TILE_PP4_128x64: launch_tile_pp<128, 64, 4, 2, 4>(k, s); break;
     default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
   }
   APTP_LAUNCH_CHECK();

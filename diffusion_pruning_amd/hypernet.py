@@ -104,7 +104,10 @@ class HyperStructure(nn.Module):
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(self.config, f)
-        torch.save(self.state_dict(), os.path.join(path, "diffusion_pytorch_model.bin"))
+        # diffusers 0.23.1 ModelMixin.save_pretrained defaults to safetensors
+        from safetensors.torch import save_file
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(path, "diffusion_pytorch_model.safetensors"))
 
     @classmethod
     def from_pretrained(cls, path: str, **kwargs):
@@ -112,5 +115,10 @@ class HyperStructure(nn.Module):
             cfg = json.load(f)
         cfg.update(kwargs)
         m = cls(**cfg)
-        m.load_state_dict(torch.load(os.path.join(path, "diffusion_pytorch_model.bin"), map_location="cpu"))
+        st = os.path.join(path, "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            m.load_state_dict(load_file(st))
+        else:   # torch-pickled weights (safe_serialization=False)
+            m.load_state_dict(torch.load(os.path.join(path, "diffusion_pytorch_model.bin"), map_location="cpu"))
         return m

@@ -1186,6 +1186,8 @@ class UNet2DConditionModelGated(nn.Module):
     def set_structure(self, arch_vectors):
         """unet_2d_conditional.py:1365-1413 — consumes (pops) the caller's width/depth lists."""
         width_vectors, depth_vectors = arch_vectors["width"], arch_vectors["depth"]
+        # kept (by reference) so a checkpoint can record the installed architecture vector (checkpoint.arch_vector_of)
+        self._installed_structure = {"width": list(width_vectors), "depth": list(depth_vectors)}
         # one bulk device->host copy of all gates so per-module mode selection needs no further syncs
         self._prefetch_hosts(width_vectors, depth_vectors)
         for m in self._containers():

@@ -94,7 +94,16 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        APTP_TILE_DMA3_128x128 = 13, APTP_TILE_DMA3_128x160 = 14, APTP_TILE_DMA3_64x128 = 15, APTP_TILE_DMA3_64x160 = 16,
        APTP_TILE_DMA3_128x64 = 17, APTP_TILE_DMA3_64x64 = 18,
        /* LDS-DMA, 8-wave (512-thread) workgroups: one weight tile shared by twice the rows */
-       APTP_TILE_DMA8_128x160 = 19, APTP_TILE_DMA8_256x160 = 20, APTP_TILE_DMA8_128x128 = 21, APTP_TILE_DMA8_256x128 = 22 };
+       APTP_TILE_DMA8_128x160 = 19, APTP_TILE_DMA8_256x160 = 20, APTP_TILE_DMA8_128x128 = 21, APTP_TILE_DMA8_256x128 = 22,
+       /* LDS-DMA, 4 waves, 4-stage ring (three operand tiles in flight) */
+       APTP_TILE_DMA4_64x160 = 23, APTP_TILE_DMA4_64x128 = 24, APTP_TILE_DMA4_64x64 = 25, APTP_TILE_DMA4_128x64 = 26,
+       APTP_TILE_DMA4_128x128 = 27,
+       /* LDS-DMA, 8 waves, 3- or 4-stage ring */
+       APTP_TILE_DMA8R3_128x160 = 28, APTP_TILE_DMA8R4_128x160 = 29, APTP_TILE_DMA8R3_128x128 = 30,
+       APTP_TILE_DMA8R4_128x128 = 31, APTP_TILE_DMA8R3_256x128 = 32,
+       /* LDS-DMA, 8 waves in two groups that alternate load and MFMA slots (ping-pong), 3- or 4-stage ring */
+       APTP_TILE_PP3_128x160 = 33, APTP_TILE_PP4_128x160 = 34, APTP_TILE_PP3_128x128 = 35, APTP_TILE_PP4_128x128 = 36,
+       APTP_TILE_PP4_64x160 = 37, APTP_TILE_PP4_64x128 = 38, APTP_TILE_PP5_64x160 = 39, APTP_TILE_PP4_128x64 = 40 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

@@ -85,6 +85,147 @@ CONV_CASES = [
     (3, 7, 5, 72, 40, 3, 1, 0, 21, 2),
     (1, 8, 8, 1280, 1280, 3, 1, 0, 22, 4),
     (2, 16, 16, 192, 128, 1, 1, 0, 20, 1),
+    # 4-stage rings (tiles 23..27), 8-wave 3/4-stage rings (28..32) and the 8-wave ping-pong schedule (33..40): several
+    # tiles in flight across the barriers, waves with different DMA counts (160-wide tile on 512 threads), K shorter than
+    # the ring, split-K slices of 1-3 steps, staggered wave groups
+    (2, 32, 32, 160, 320, 3, 1, 0, 23, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 23, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 23, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 23, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 23, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 23, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 23, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 24, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 24, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 24, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 24, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 24, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 24, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 24, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 25, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 25, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 25, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 25, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 25, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 25, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 25, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 26, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 26, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 26, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 26, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 26, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 26, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 26, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 27, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 27, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 27, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 27, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 27, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 27, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 27, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 28, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 28, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 28, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 28, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 28, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 28, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 28, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 29, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 29, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 29, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 29, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 29, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 29, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 29, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 30, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 30, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 30, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 30, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 30, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 30, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 30, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 31, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 31, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 31, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 31, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 31, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 31, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 31, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 32, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 32, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 32, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 32, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 32, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 32, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 32, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 33, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 33, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 33, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 33, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 33, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 33, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 33, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 34, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 34, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 34, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 34, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 34, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 34, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 34, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 35, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 35, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 35, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 35, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 35, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 35, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 35, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 36, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 36, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 36, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 36, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 36, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 36, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 36, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 37, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 37, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 37, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 37, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 37, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 37, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 37, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 38, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 38, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 38, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 38, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 38, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 38, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 38, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 39, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 39, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 39, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 39, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 39, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 39, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 39, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 40, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 40, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0, 40, 1),
+    (2, 16, 16, 128, 128, 1, 1, 0, 40, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 40, 4),
+    (2, 8, 8, 128, 128, 3, 1, 1, 40, 3),
+    (2, 16, 16, 128, 128, 3, 2, 0, 40, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 23, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 29, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 28, 1),
+    (4, 32, 32, 1280, 640, 3, 1, 0, 31, 3),
+    (4, 32, 32, 1280, 640, 3, 1, 0, 32, 2),
+    (4, 64, 64, 320, 320, 3, 1, 0, 33, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 34, 1),
+    (4, 64, 64, 320, 160, 3, 1, 0, 37, 1),
+    (4, 64, 64, 320, 160, 3, 1, 0, 39, 1),
+    (4, 32, 32, 1280, 640, 3, 1, 0, 36, 3),
+    (4, 32, 32, 640, 640, 3, 1, 0, 38, 1),
+    (4, 32, 32, 640, 640, 3, 1, 0, 40, 1),
 ]
 
 

@@ -194,15 +194,17 @@ def measure_roofline(ops, step, dev):
     # HBM-side bytes per launch of this kernel family come from separate rocprofv3 --pmc passes over this same command
     # (FETCH_SIZE and WRITE_SIZE cannot share a pass; gfx950 FETCH_SIZE correction applied) committed under profiles/.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r1f_pmc_traffic.json")
-    if os.path.exists(tpath):
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if tpaths:
         try:
-            with open(tpath) as fh:
+            with open(tpaths[-1]) as fh:       # the latest round's passes (tools/pmc_traffic.py)
                 traffic = round(json.load(fh)["hbm_side_bytes_per_launch"])
-            traffic_src = "profiles/r1f_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, bytes per launch)"
+            traffic_src = ("profiles/" + os.path.basename(tpaths[-1]) +
+                           " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, bytes per launch)")
         except Exception:  # noqa: BLE001
             traffic = None
-    return {"bound": "mfma", "kernel": "conv_gemm_kernel<BM,BN,2,2> (implicit-GEMM conv/linear, all tile instantiations)",
+    return {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<BM,BN,WM,WN,STAGES,PP> / conv_gemm_kernel (implicit-GEMM conv/linear, all tile instantiations)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n, "avg_launch_us": round(total_ms * 1e3 / n, 2),
             "family_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(flops / 1e9, 1)}

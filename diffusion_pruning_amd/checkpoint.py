@@ -198,8 +198,13 @@ def arch_vector_of(model: UNet2DConditionModelGated) -> torch.Tensor:
     return torch.cat(parts, dim=1)
 
 
-def from_pretrained(root: str, subfolder: str = "unet", cls=None, arch_vector: Optional[torch.Tensor] = None,
-                    random_pruning_ratio: Optional[float] = None, device=None):
+_CONFIG_KEYS = ("sample_size", "in_channels", "out_channels", "down_block_types", "mid_block_type", "up_block_types",
+                "block_out_channels", "layers_per_block", "cross_attention_dim", "attention_head_dim", "norm_num_groups",
+                "norm_eps", "gated_ff", "ff_gate_width")
+
+
+def from_pretrained(root: str, subfolder: Optional[str] = "unet", cls=None, arch_vector: Optional[torch.Tensor] = None,
+                    random_pruning_ratio: Optional[float] = None, device=None, **overrides):
     """Build the model named in ``config.json`` (or ``cls``), install the architecture vector for a pruned expert
     (``arch_vector`` argument, else ``<root>/arch_vector.pt``, else a random one at ``random_pruning_ratio``:
     unet_2d_conditional.py:2409-2436) and load the weights."""
@@ -209,14 +214,23 @@ def from_pretrained(root: str, subfolder: str = "unet", cls=None, arch_vector: O
         cfg = json.load(f)
     name = cfg.pop("_class_name", "UNet2DConditionModelGated")
     cfg.pop("_aptp_format", None)
-    cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    cfg = {k: v for k, v in cfg.items() if k in _CONFIG_KEYS}
+    cfg.update({k: v for k, v in overrides.items() if k in _CONFIG_KEYS and v is not None})
     if cls is None:
         cls = UNet2DConditionModelPruned if name == "UNet2DConditionModelPruned" else UNet2DConditionModelGated
     model = cls.from_config(cfg)
     sd = load_file(os.path.join(d, WEIGHTS_NAME))
     if issubclass(cls, UNet2DConditionModelPruned):
-        if arch_vector is None and os.path.exists(os.path.join(root, ARCH_VECTOR_NAME)):
-            arch_vector = torch.load(os.path.join(root, ARCH_VECTOR_NAME))
+        if arch_vector is None:
+            # the reference looks in subfolder.rsplit('/', 1)[0] (unet_2d_conditional.py:2412-2414); scripts keep the file
+            # beside unet/ (generate_fid_images.py:88)
+            cands = [os.path.join(root, ARCH_VECTOR_NAME)]
+            if subfolder:
+                cands.insert(0, os.path.join(root, subfolder.rsplit("/", 1)[0], ARCH_VECTOR_NAME))
+            for c in cands:
+                if os.path.exists(c):
+                    arch_vector = torch.load(c, map_location="cpu")
+                    break
         if random_pruning_ratio is not None:
             arch_vector = HyperStructure.get_random_arch_vector(random_pruning_ratio, model.get_structure())
         if arch_vector is None:

@@ -23,6 +23,8 @@ Differences that matter (all deliberate):
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple, Union
@@ -1162,6 +1164,23 @@ class UNet2DConditionModelGated(nn.Module):
         self.invalidate_plans()
         return out
 
+    # ---- checkpoints in the reference's on-disk layout (diffusers ModelMixin API; checkpoint.py) -------------------
+    def save_pretrained(self, save_directory: str, **unused):
+        """``model.save_pretrained(os.path.join(output_dir, "unet"))`` as trainer.py:262-265 calls it: config.json +
+        diffusion_pytorch_model.safetensors in ``save_directory`` (a pruned expert at its sliced shapes, with
+        arch_vector.pt in the parent directory)."""
+        from . import checkpoint
+        root, sub = os.path.split(os.path.normpath(save_directory))
+        checkpoint.save_pretrained(self, root, subfolder=sub)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, subfolder: Optional[str] = None, **kwargs):
+        """unet_2d_conditional.py:2184-2472 for local directories: ``arch_vector=`` / ``random_pruning_ratio=`` select the
+        structure of a pruned expert, configuration keys (``down_block_types`` …) override config.json, hub-only keyword
+        arguments (``revision``, ``cache_dir`` …) are ignored."""
+        from . import checkpoint
+        return checkpoint.from_pretrained(pretrained_model_name_or_path, subfolder=subfolder, cls=cls, **kwargs)
+
     # ---- reference API --------------------------------------------------------------------------------------------
     def freeze(self):
         # unet_2d_conditional.py:2118-2122: gate_f is a plain attribute, so this freezes every parameter (quirk Q2)
@@ -1488,6 +1507,17 @@ class UNet2DConditionModelPruned(UNet2DConditionModelGated):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.semantics = "pruned"
+
+    def load_state_dict(self, state_dict, strict: bool = True, **k):
+        """A pruned expert's file holds sliced tensors (the reference's modules are physically sliced, and
+        scripts/metrics/generate_fid_images.py:99-101 loads such a file into the pruned model): scatter them into the live
+        rows / columns of the full-shape masters.  Full-shape state dicts load as usual."""
+        own = self.state_dict()
+        full = all(kk in state_dict and tuple(state_dict[kk].shape) == tuple(v.shape) for kk, v in own.items())
+        if full or not getattr(self, "_installed_structure", None):
+            return super().load_state_dict(state_dict, strict=strict, **k)
+        from . import checkpoint
+        return checkpoint.load_pruned_state_dict(self, state_dict, strict=strict)
 
     def prune(self, arch_vectors):
         """Binarise the architecture code with hard_concrete's threshold (estimation_utils.py:67-75), install it and

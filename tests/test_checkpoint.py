@@ -161,3 +161,28 @@ def test_router_checkpoint_layout(tmp_path):
     assert all(torch.equal(v, q2.state_dict()[k]) for k, v in q.state_dict().items())
     hn3 = HyperStructure.from_pretrained(str(tmp_path / "hypernet"))
     assert hn3.config["input_dim"] == 32
+
+
+def test_modelmixin_style_api_as_the_reference_scripts_use_it(tmp_path):
+    """trainer.py:262-265 (model.save_pretrained(<dir>/unet)) and generate_fid_images.py:88-101
+    (from_pretrained(sd21, subfolder="unet", arch_vector=...) then load_state_dict(pruned safetensors))."""
+    from safetensors.torch import load_file
+    cfg, dense = _tiny()
+    dense.save_pretrained(str(tmp_path / "sd21" / "unet"))                       # stands in for the SD-2.1 folder
+    soft = _soft_mask(cfg, 0.5, 21, 2)
+    av = torch.cat([t.reshape(1, -1) for t in soft["width"] + soft["depth"]], dim=1)
+    # a fine-tuned expert: different live weights
+    expert = UNet2DConditionModelPruned.from_pretrained(str(tmp_path / "sd21"), subfolder="unet", arch_vector=av,
+                                                        revision=None, down_block_types=None)
+    with torch.no_grad():
+        for p_ in expert.parameters():
+            p_.add_(0.01)
+    expert.save_pretrained(str(tmp_path / "ft" / "unet"))
+    assert os.path.exists(tmp_path / "ft" / "arch_vector.pt")
+    arch_v = torch.load(tmp_path / "ft" / "arch_vector.pt", map_location="cpu")
+    unet = UNet2DConditionModelPruned.from_pretrained(str(tmp_path / "sd21"), subfolder="unet", arch_vector=arch_v)
+    sd = load_file(str(tmp_path / "ft" / "unet" / "diffusion_pytorch_model.safetensors"))
+    assert any(tuple(v.shape) != tuple(unet.state_dict()[k].shape) for k, v in sd.items())   # sliced shapes on disk
+    unet.load_state_dict(sd)
+    a, b = C.pruned_state_dict(expert), C.pruned_state_dict(unet)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)

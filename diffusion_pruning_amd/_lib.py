@@ -38,7 +38,7 @@ class ConvGemmParams(Structure):
         ("y", c_void_p), ("ldy", c_int64),
         ("out_f32", c_int32), ("split_k", c_int32),
         ("workspace", c_void_p),
-        ("tile", c_int32),
+        ("tile", c_int32), ("order", c_int32),
     ]
 
 

@@ -146,28 +146,27 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     }
     // sacc[t][r] = score(key = tile*64 + 32t + (r&3) + 8(r>>2) + 4hh, query = q0 + lq)
     const int key_base = tile * 64 + 4 * hh;
+    // VALU budget (the level-64 self-attention is exp/VALU-bound, not MFMA-bound): the softmax scale is folded into the
+    // exp2 argument (one fma per score instead of a multiply pass + a subtract), the running maximum is taken over the
+    // raw scores (c > 0), and the accumulator is only rescaled when some lane's maximum moved.
     float mx = -INFINITY;
     if (tile * 64 + 64 <= p.Lk) {              // full tile (wave-uniform): no key masking
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float sv = sacc[t][r] * p.c;
-          sacc[t][r] = sv;
-          mx = fmaxf(mx, sv);
-        }
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[t][r], sacc[t][r + 1]));
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key_base + 32 * t + (r & 3) + 8 * (r >> 2);
-          const float sv = key < p.Lk ? sacc[t][r] * p.c : -INFINITY;
+          const float sv = key < p.Lk ? sacc[t][r] : -INFINITY;
           sacc[t][r] = sv;
           mx = fmaxf(mx, sv);
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.c;
     const float m_new = fmaxf(m_run, mx);       // finite: every tile holds >= 1 valid key
     const float alpha = exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
     float rs = 0.f;
@@ -175,17 +174,19 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(sacc[t][r] - m_new);
+        const float pv = exp2f(__builtin_fmaf(sacc[t][r], p.c, -m_new));   // masked keys: -inf * c - m = -inf -> 0
         sacc[t][r] = pv;
         rs += pv;
       }
     rs += __shfl_xor(rs, 32);
     l_run = l_run * alpha + rs;
     m_run = m_new;
+    if (!__all(alpha == 1.0f)) {                // wave-uniform: after the first tiles the maximum rarely moves
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+    }
 
     // ---- O^T += V^T . P^T ----------------------------------------------------------------------------------------
 #pragma unroll

@@ -46,7 +46,48 @@ struct KParams {
   int x_bytes, w_bytes;     // buffer-resource extents (bytes)
   int M, HW, Nout;          // Nout = logical output columns (N/2 for GEGLU)
   int64_t ws_ld;            // workspace row stride (floats)
+  int order;                // workgroup -> tile order (decode_block): 0 legacy, 1 weight-major, 2 activation-major
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// XCD-aware workgroup -> (M-tile, N-tile, K-slice) mapping.  Workgroups are dealt round-robin over the 8 XCDs
+// (linear id % 8) and every XCD has its own 4 MiB L2, so the legacy order (N-tile fastest) makes each XCD stream the
+// WHOLE weight matrix and the whole activation tensor: with 8 L2s that is up to 8x the operand bytes on the fabric
+// (measured 10.7 GB beyond L2 per step against 2.9 GB algorithmic).  Here each XCD gets one contiguous range of a
+// work order in which neighbours share an operand:
+//   order 1 (weight-major, weights larger than the activation tensor: levels 16/8): q -> (weight slice = (N-tile,
+//            K-slice), M-tile fastest): the weight matrix is PARTITIONED over the XCDs, the small activation tensor
+//            is what gets replicated;
+//   order 2 (activation-major, levels 64/32): q -> (M-tile, then N-tile / K-slice fastest): each XCD owns a contiguous
+//            band of output rows (3x3 halos of neighbouring tiles hit its L2), the small weight matrix is replicated.
+// The (xcd, j) -> q map is the bijective remap for any workgroup count (cdna_hip_programming.md, 256^2 template).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void decode_block(const KParams& p, int tiles_m, int tiles_n, int& tm, int& tn, int& kz) {
+  const int L = blockIdx.x;
+  if (p.order == 0) {
+    const int t = L % (tiles_m * tiles_n);
+    kz = L / (tiles_m * tiles_n);
+    tn = t % tiles_n;
+    tm = t / tiles_n;
+    return;
+  }
+  const int T = gridDim.x;
+  const int xcd = L & 7, j = L >> 3;
+  const int qq = T >> 3, r = T & 7;
+  const int q = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + j;
+  if (p.order == 1) {
+    tm = q % tiles_m;
+    const int w = q / tiles_m;          // weight slice: K-slice fastest, so an XCD's slices of one N-tile are adjacent
+    kz = w % p.split_k;
+    tn = w / p.split_k;
+  } else {
+    const int per_m = tiles_n * p.split_k;
+    tm = q / per_m;
+    const int rest = q - tm * per_m;
+    tn = rest % tiles_n;
+    kz = rest / tiles_n;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // epilogue for 4 consecutive (packed) columns of one output row.  Shared by the GEMM kernel and the split-K reducer.
@@ -144,9 +185,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int tm, tn, kz;
+  decode_block(p, tiles_m, tiles_n, tm, tn, kz);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kz = blockIdx.y;
   const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
   const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
 
@@ -363,9 +405,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases stay scalar
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int tm, tn, kz;
+  decode_block(p, tiles_m, tiles_n, tm, tn, kz);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kz = blockIdx.y;
   const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
   const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
 
@@ -657,7 +700,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   }
 
 #ifdef APTP_STAMPS
-  if (lane == 0 && blockIdx.y == 0) {
+  if (lane == 0 && kz == 0) {
     const int slot = (blockIdx.x * NW + wave) & 4095;
     g_stamps[slot * 4 + 0] = st_acc[0]; g_stamps[slot * 4 + 1] = st_acc[1]; g_stamps[slot * 4 + 2] = st_acc[2];
     g_stamps[slot * 4 + 3] = __builtin_readcyclecounter() - st_begin;
@@ -802,6 +845,15 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   k.ws = (float*)p->workspace;
   k.M = (int)M64; k.HW = p->Hout * p->Wout; k.Nout = nout;
   k.ws_ld = p->N;
+  APTP_CHECK(p->order >= 0 && p->order <= 3, "conv_gemm: order %d", p->order);
+  if (p->order == 0) {
+    // auto: partition over the XCDs whichever operand is larger; the other one is replicated in every XCD's L2
+    const int64_t w_bytes = (int64_t)p->N * k.Ktot * 2;
+    const int64_t a_bytes = (int64_t)p->B * p->Hin * p->Win * p->Cin * 2;
+    k.order = w_bytes > a_bytes ? 1 : 2;
+  } else {
+    k.order = p->order - 1;   // 1 legacy, 2 weight-major, 3 activation-major
+  }
   const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * 2;
   const int64_t wb = (int64_t)p->N * k.Ktot * 2;
   APTP_CHECK(xb < (1ll << 31) && wb < (1ll << 31), "conv_gemm: operand larger than 2 GiB");
@@ -812,14 +864,14 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
 template <int BM, int BN>
 void launch_tile(const KParams& k, hipStream_t s) {
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
-  dim3 grid(tiles, k.split_k, 1);
+  dim3 grid(tiles * k.split_k, 1, 1);
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
 }
 
 template <int BM, int BN, int STAGES>
 void launch_tile_dma(const KParams& k, hipStream_t s) {
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
-  dim3 grid(tiles, k.split_k, 1);
+  dim3 grid(tiles * k.split_k, 1, 1);
   hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, 2, STAGES>), grid, dim3(256), 0, s, k);
 }
 
@@ -827,7 +879,7 @@ void launch_tile_dma(const KParams& k, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int STAGES = 2>
 void launch_tile_dma8(const KParams& k, hipStream_t s) {
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
-  dim3 grid(tiles, k.split_k, 1);
+  dim3 grid(tiles * k.split_k, 1, 1);
   hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(512), 0, s, k);
 }
 
@@ -835,7 +887,7 @@ void launch_tile_dma8(const KParams& k, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int STAGES>
 void launch_tile_pp(const KParams& k, hipStream_t s) {
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
-  dim3 grid(tiles, k.split_k, 1);
+  dim3 grid(tiles * k.split_k, 1, 1);
   hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, true>), grid, dim3(512), 0, s, k);
 }
 

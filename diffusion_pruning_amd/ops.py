@@ -178,7 +178,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               colgate: Optional[torch.Tensor] = None, gate_group: int = 0, act: int = ACT_NONE,
               corr: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
-              out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0) -> torch.Tensor:
+              out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0) -> torch.Tensor:
     """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites."""
     lib = _lib.load()
     _check_act(x, "conv_gemm x")
@@ -232,11 +232,14 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         p.depth_in, p.lddin = depth_in.data_ptr(), _ld(depth_in)
     p.y, p.ldy, p.out_f32 = out.data_ptr(), _ld(out), int(out_f32)
     p.tile = tile
+    p.order = order
     p.split_k = 1
     if split_k is None and tile == 0:
         tuned = TUNING.get(tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU))
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
+            if order == 0:
+                p.order = tuned.get("order", 1)     # tables tuned before the XCD-aware orders existed mean the legacy order
     if split_k is None:
         split_k = lib.aptp_conv_gemm_suggest_split_k(ctypes.byref(p))
     p.split_k = max(1, int(split_k))

@@ -83,6 +83,8 @@ typedef struct {
   int32_t split_k;      /* >=1; >1 needs workspace of aptp_conv_gemm_workspace_bytes() */
   void* workspace;
   int32_t tile;         /* 0 = auto; otherwise APTP_TILE_* (testing / tuning) */
+  int32_t order;        /* workgroup -> tile order over the 8 XCDs: 0 = auto (partition the larger operand), 1 = legacy
+                         * (N-tile fastest), 2 = weight-major, 3 = activation-major (testing / tuning) */
 } AptpConvGemmParams;
 
 enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TILE_64x128 = 3, APTP_TILE_64x160 = 4,

@@ -248,6 +248,32 @@ def test_conv_plain(ops, cuda, case):
     assert e <= REL_L2_TOL, f"rel-L2 {e:.3e}"
 
 
+ORDER_CASES = [
+    # B, H, W, Cin, Cout, k, tile, split_k : workgroup counts that are / are not multiples of 8, with and without split-K
+    (2, 32, 32, 160, 320, 3, 10, 1),     # 32 x 2 tiles
+    (3, 7, 5, 72, 40, 3, 12, 1),         # 2 x 1 tiles (< 8 workgroups)
+    (1, 24, 24, 64, 200, 3, 12, 3),      # 9 x 4 tiles x 3 slices = 108
+    (1, 8, 8, 1280, 1280, 3, 18, 5),     # 1 x 20 x 5
+    (4, 16, 16, 320, 136, 3, 34, 2),     # ping-pong tile, 8 x 1 x 2
+    (2, 40, 40, 64, 64, 1, 6, 1),        # 50 x 1 (register-staged kernel)
+]
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("case", ORDER_CASES)
+def test_conv_workgroup_orders_agree(ops, cuda, case, order):
+    """every XCD-aware workgroup -> tile order computes the same tiles: bit-identical to the legacy order"""
+    B, H, W, Cin, Cout, k, tile, split_k = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = nhwc(_rand((B, Cin, H, W), g).bfloat16()).to(cuda)
+    pw = ops.pack_weight(_rand((Cout, Cin, k, k), g, 1.0 / math.sqrt(Cin * k * k)), _rand((Cout,), g, 0.1), device=cuda)
+    ref = ops.conv_gemm(x, pw, tile=tile, split_k=split_k, order=1)
+    y = ops.conv_gemm(x, pw, tile=tile, split_k=split_k, order=order)
+    assert torch.equal(y, ref)
+    auto = ops.conv_gemm(x, pw, tile=tile, split_k=split_k)
+    assert torch.equal(auto, ref)
+
+
 def test_conv_strided_views(ops, cuda):
     """input is a channel slice of a wider buffer, output written into a slice of a wider buffer"""
     g = torch.Generator().manual_seed(7)

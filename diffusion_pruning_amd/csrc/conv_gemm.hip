@@ -785,8 +785,8 @@ const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, 
                           {64, 160}, {64, 128}, {64, 64}, {128, 64}, {128, 128},                // 23..27: LDS-DMA, 4 stages
                           {128, 160}, {128, 160}, {128, 128}, {128, 128}, {256, 128},           // 28..32: 8 waves, 3/4-stage ring
                           {128, 160}, {128, 160}, {128, 128}, {128, 128}, {64, 160}, {64, 128}, // 33..38: 8 waves, ping-pong
-                          {64, 160}, {128, 64}};                                                // 39..40
-constexpr int kNumTiles = 41;
+                          {64, 160}, {128, 64}, {256, 128}, {128, 256}};                        // 39..42
+constexpr int kNumTiles = 43;
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
   if (p->tile != APTP_TILE_AUTO) return p->tile;
@@ -976,6 +976,8 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_PP4_64x128: launch_tile_pp<64, 128, 2, 4, 4>(k, s); break;
     case APTP_TILE_PP5_64x160: launch_tile_pp<64, 160, 4, 2, 5>(k, s); break;
     case APTP_TILE_PP4_128x64: launch_tile_pp<128, 64, 4, 2, 4>(k, s); break;
+    case APTP_TILE_PP3_256x128: launch_tile_pp<256, 128, 4, 2, 3>(k, s); break;
+    case APTP_TILE_PP3_128x256: launch_tile_pp<128, 256, 2, 4, 3>(k, s); break;
     default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
   }
   APTP_LAUNCH_CHECK();

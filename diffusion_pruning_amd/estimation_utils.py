@@ -45,9 +45,12 @@ def gumbel_softmax_sample(logits, temperature, offset=0, force_width_non_zero=Fa
     return vector_gumbel_softmax(logits, temperature, offset, force_width_non_zero, fixed_seed)
 
 
-def importance_gumbel_softmax_sample(logits, temperature, offset=0, fixed_seed=False):
-    """estimation_utils.py:49-64: softmax -> cumsum -> flip gives monotone keep-probabilities; logit with eps=1e-6."""
+def importance_gumbel_softmax_sample(logits, temperature, offset=0, fixed_seed=False, noise=None):
+    """estimation_utils.py:49-64: softmax -> cumsum -> flip gives monotone keep-probabilities; logit with eps=1e-6.
+    noise: Gumbel noise already drawn (in the reference's order) and moved to the device by the caller."""
     p = torch.flip(torch.cumsum(torch.softmax(logits, dim=1), dim=1), dims=[1])
     eps = 1e-6
     x = torch.log(p + eps) - torch.log1p(-(p - eps))
+    if noise is not None:
+        return torch.sigmoid((x + noise + offset) / temperature)
     return _noisy_sigmoid(x, temperature, offset, fixed_seed)

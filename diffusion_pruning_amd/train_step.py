@@ -202,6 +202,172 @@ class PrunerStep:
         return out
 
 
+class GraphedPrunerStep(PrunerStep):
+    """PrunerStep with the two U-Net passes replayed from HIP graphs.
+
+    The pruning step is host-bound when run eagerly (≈10^4 launches per step at SD-2.1 size: two U-Net forwards, one
+    backward, autograd glue).  Everything that touches the U-Net has static shapes, so it is captured once:
+
+    * ``g_teacher``: the all-ones (dense) forward under no_grad -> ``full_pred`` and the 9 block activations;
+    * ``g_student``: forward with the architecture code read from STATIC gate buffers, the three U-Net loss terms
+      (min-SNR diffusion MSE, output distillation, block distillation: trainer.py:1197-1225) and the backward down to the
+      gradient of those terms w.r.t. every gate buffer.
+
+    Each step the router runs eagerly (it draws host-side Gumbel noise, quirk Q6, and is tiny), its 84 gate tensors are
+    copied into the static buffers, the graphs are replayed, and the chain rule is closed eagerly:
+    ``autograd.backward([router-only losses] + gate tensors, [None] + captured gate gradients)``.
+    Losses and router gradients equal the eager step's (tests/test_train_step_gpu.py)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._cap = None
+
+    # ---- capture ------------------------------------------------------------------------------------------------
+    def _snr_weights(self, timesteps):
+        """min-SNR-gamma weights (trainer.py:1203-1213); host tables are involved, so this stays outside the graphs"""
+        cfg = self.cfg
+        if cfg.snr_gamma is None:
+            return torch.ones(timesteps.shape[0], device=timesteps.device)
+        snr = compute_snr(self.schedule, timesteps)
+        if cfg.prediction_type == "v_prediction":
+            snr = snr + 1
+        return (torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr).float()
+
+    def _schedule_on(self, device):
+        # keep the alpha-bar table on the device: a pageable host->device copy per step would make the host wait for the
+        # previous step's graphs
+        if self.schedule.alphas_cumprod.device != device:
+            self.schedule.alphas_cumprod = self.schedule.alphas_cumprod.to(device)
+
+    def _unet_losses(self, model_pred, student_acts, full_pred, teacher_acts, w, target):
+        cfg = self.cfg
+        if cfg.snr_gamma is None:
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+        else:
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
+            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
+        distillation_loss = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")
+        block_loss = torch.zeros((), device=model_pred.device)
+        for k in student_acts:
+            block_loss = block_loss + F.mse_loss(student_acts[k].float(), teacher_acts[k].detach().float(), reduction="mean")
+        block_loss = block_loss / len(student_acts)
+        return loss, distillation_loss, block_loss
+
+    def capture(self, batch: dict):
+        """Capture both graphs for this batch geometry (call once; later batches must have the same shapes)."""
+        cfg = self.cfg
+        dev = batch["noisy_latents"].device
+        st = {k: batch[k].clone() for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target")}
+        self._schedule_on(dev)
+        st["snr_w"] = self._snr_weights(st["timesteps"])
+        B = st["noisy_latents"].shape[0]
+        ones = torch.ones((B, self.quantizer.vq_embed_dim), device=dev)
+        full = self.hyper_net.transform_structure_vector(ones)
+        proto = self.hyper_net.transform_structure_vector(ones)
+        gw = [t.detach().clone().requires_grad_(True) for t in proto["width"]]
+        gd = [t.detach().clone().requires_grad_(True) for t in proto["depth"]]
+
+        def teacher():
+            with torch.no_grad():
+                pred = self.unet(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
+                return pred, dict(self.block_activations)
+
+        def student(full_pred, teacher_acts):
+            pred = self.unet(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
+            acts = dict(self.block_activations)
+            loss, dist, blk = self._unet_losses(pred, acts, full_pred, teacher_acts, st["snr_w"], st["target"])
+            total = loss + cfg.distillation_weight * dist + cfg.block_weight * blk
+            grads = torch.autograd.grad(total, gw + gd, allow_unused=True)
+            grads = [torch.zeros_like(t) if g is None else g for g, t in zip(grads, gw + gd)]
+            return loss.detach(), dist.detach(), blk.detach(), grads
+
+        # warm-up on a side stream (allocator / plan caches), then capture: the module state at capture time decides what
+        # is baked in, so the structure is installed right before each capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.unet.set_structure({"width": list(full["width"]), "depth": list(full["depth"])})
+            fp, ta = teacher()
+            self.unet.set_structure({"width": list(gw), "depth": list(gd)})
+            student(fp, ta)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        self.unet.set_structure({"width": list(full["width"]), "depth": list(full["depth"])})
+        g_teacher = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_teacher):
+            full_pred, teacher_acts = teacher()
+        self.unet.set_structure({"width": list(gw), "depth": list(gd)})
+        g_student = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_student, pool=g_teacher.pool()):
+            loss, dist, blk, grads = student(full_pred, teacher_acts)
+        self._cap = dict(st=st, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, loss=loss, dist=dist, blk=blk,
+                         grads=grads, full_pred=full_pred)
+        return self
+
+    # ---- one step -------------------------------------------------------------------------------------------------------
+    def step(self, noisy_latents, timesteps, encoder_hidden_states, text_embeddings, target, pretrain: bool = False):
+        if self._cap is None:
+            return super().step(noisy_latents, timesteps, encoder_hidden_states, text_embeddings, target, pretrain)
+        cfg, cap = self.cfg, self._cap
+        arch_vector = self.hyper_net(text_embeddings)
+        arch_vector_quantized, _ = self.quantizer(arch_vector)
+        arch_vector = self.quantizer.gumbel_sigmoid_trick(arch_vector)
+        arch_wdn = self.quantizer.width_depth_normalize(arch_vector)
+        text_all, arch_all = gather_with_local_grad(text_embeddings, arch_wdn)
+        sep = self.hyper_net.transform_structure_vector(arch_vector if pretrain else arch_vector_quantized)
+        contrastive_loss = self.contrastive(text_all, arch_all)
+        pieces = list(sep["width"]) + list(sep["depth"])
+
+        # MAC accounting is differentiable in the gates (calc_macs family): feed it the router-connected tensors.  Done
+        # BEFORE the replays are queued and without the host classification copy, so the host never waits on the graphs.
+        self.unet.set_structure({"width": list(sep["width"]), "depth": list(sep["depth"])}, prefetch_hosts=False)
+        macs = self.unet.calc_macs()
+        ratios = macs["cur_prunable_macs"] / self.unet.resource_info_dict["cur_prunable_macs"].squeeze()
+        resource_loss = self.resource(ratios.mean())
+        max_loss = 1.0 - torch.max(ratios)
+        std_loss = -torch.std(ratios)
+
+        with torch.no_grad():
+            for k, src in (("noisy_latents", noisy_latents), ("timesteps", timesteps),
+                           ("encoder_hidden_states", encoder_hidden_states), ("target", target)):
+                cap["st"][k].copy_(src)
+            cap["st"]["snr_w"].copy_(self._snr_weights(timesteps))
+            for dst, src in zip(cap["gw"] + cap["gd"], pieces):
+                dst.copy_(src.reshape(dst.shape))
+        cap["g_teacher"].replay()
+        cap["g_student"].replay()
+
+        router_loss = cfg.resource_weight * resource_loss + cfg.contrastive_weight * contrastive_loss \
+            + cfg.std_weight * std_loss + cfg.max_weight * max_loss
+        unet_loss = cap["loss"] + cfg.distillation_weight * cap["dist"] + cfg.block_weight * cap["blk"]
+        gate_grads = [g.reshape(p.shape) for g, p in zip(cap["grads"], pieces)]
+        return {"loss": (router_loss.detach() + unet_loss).clone(), "diff_loss": cap["loss"].clone(),
+                "distillation_loss": cap["dist"].clone(), "block_loss": cap["blk"].clone(),
+                "contrastive_loss": contrastive_loss.detach(), "resource_loss": resource_loss.detach(),
+                "resource_ratio": ratios.mean().detach(), "arch_vector_quantized": arch_vector_quantized.detach(),
+                "_router_loss": router_loss, "_gate_tensors": pieces, "_gate_grads": gate_grads}
+
+    @staticmethod
+    def backward(out: dict):
+        """Close the chain rule: d(total)/d(router) = d(router-only terms) + sum_g dL_unet/dgate_g * dgate_g/d(router)."""
+        if "_router_loss" not in out:
+            out["loss"].backward()
+            return
+        ts = [t for t in out["_gate_tensors"] if t.requires_grad]
+        gs = [g for t, g in zip(out["_gate_tensors"], out["_gate_grads"]) if t.requires_grad]
+        torch.autograd.backward([out["_router_loss"]] + ts, [None] + gs)
+
+    def train_step(self, optimizer, batch: dict, pretrain: bool = False):
+        optimizer.zero_grad(set_to_none=True)
+        out = self.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"],
+                        batch["mpnet_embeddings"], batch["target"], pretrain=pretrain)
+        self.backward(out)
+        allreduce_mean_grads(self.trainable_parameters())
+        optimizer.step()
+        return out
+
+
 def synthetic_batch(batch: int, latent: int, device, seed: int = 1234, cross_dim: int = 1024, text_dim: int = 768):
     """SURVEY §8d synthetic CC3M-shape batch: latents/target N(0,1), text states N(0,1), MPNet embeddings 0.05*N(0,1),
     random integer timesteps."""

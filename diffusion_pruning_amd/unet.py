@@ -1202,13 +1202,17 @@ class UNet2DConditionModelGated(nn.Module):
             self.structure = structure
         return self.structure
 
-    def set_structure(self, arch_vectors):
-        """unet_2d_conditional.py:1365-1413 — consumes (pops) the caller's width/depth lists."""
+    def set_structure(self, arch_vectors, prefetch_hosts: bool = True):
+        """unet_2d_conditional.py:1365-1413 — consumes (pops) the caller's width/depth lists.
+        prefetch_hosts=False skips the bulk device->host copy (a stream synchronisation) that classifies the gates as
+        hard / soft for the next forward; for callers that only need the gates installed (MAC accounting)."""
         width_vectors, depth_vectors = arch_vectors["width"], arch_vectors["depth"]
         # kept (by reference) so a checkpoint can record the installed architecture vector (checkpoint.arch_vector_of)
         self._installed_structure = {"width": list(width_vectors), "depth": list(depth_vectors)}
         # one bulk device->host copy of all gates so per-module mode selection needs no further syncs
-        self._prefetch_hosts(width_vectors, depth_vectors)
+        self._host_map = {}
+        if prefetch_hosts:
+            self._prefetch_hosts(width_vectors, depth_vectors)
         for m in self._containers():
             s = m.get_gate_structure()
             block_vectors = {"width": [], "depth": []}

@@ -105,7 +105,8 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        APTP_TILE_DMA8R4_128x128 = 31, APTP_TILE_DMA8R3_256x128 = 32,
        /* LDS-DMA, 8 waves in two groups that alternate load and MFMA slots (ping-pong), 3- or 4-stage ring */
        APTP_TILE_PP3_128x160 = 33, APTP_TILE_PP4_128x160 = 34, APTP_TILE_PP3_128x128 = 35, APTP_TILE_PP4_128x128 = 36,
-       APTP_TILE_PP4_64x160 = 37, APTP_TILE_PP4_64x128 = 38, APTP_TILE_PP5_64x160 = 39, APTP_TILE_PP4_128x64 = 40 };
+       APTP_TILE_PP4_64x160 = 37, APTP_TILE_PP4_64x128 = 38, APTP_TILE_PP5_64x160 = 39, APTP_TILE_PP4_128x64 = 40,
+       APTP_TILE_PP3_256x128 = 41, APTP_TILE_PP3_128x256 = 42 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

@@ -122,3 +122,67 @@ def test_product_rejects_cpu_tensors_without_the_emulator():
     sample, t, ehs = O.synthetic_inputs(cfg, 1, 16)
     with pytest.raises(Exception):
         model(sample, t, ehs)
+
+
+def test_vectorised_relaxation_equals_the_per_segment_loop():
+    """quantizer.gumbel_sigmoid_trick / width_depth_normalize are evaluated as whole-vector passes; the reference loops
+    over the 70 width segments / 14 depth-gated blocks (quantizer.py:196-261).  Same host-RNG stream, same values, same
+    gradients, including the non-zero-width rule on segments whose relaxation is dead."""
+    import torch
+    from diffusion_pruning_amd.estimation_utils import (gumbel_softmax_sample, hard_concrete,
+                                                        importance_gumbel_softmax_sample)
+    from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    from oracle import unet_oracle as O
+    cfg = O.TINY
+    st = UNet2DConditionModelGated(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
+                                   cross_attention_dim=cfg.cross_attention_dim).get_structure()
+    q = StructureVectorQuantizer(n_e=4, structure=st, temperature=0.4, base=3, resource_aware_normalization=False)
+    q.train()
+    nw = sum(q.width_list)
+    torch.manual_seed(0)
+    z = torch.randn(3, q.vq_embed_dim)
+    s0 = 0
+    for j, w in enumerate(q.width_list):          # kill a few segments (row 1) so the +0.5 rule fires
+        if j % 9 == 0:
+            z[1, s0:s0 + w] = -40.0
+        s0 += w
+    z1 = z.clone().requires_grad_(True)
+    z2 = z.clone().requires_grad_(True)
+
+    torch.manual_seed(77)
+    got = q.gumbel_sigmoid_trick(z1)
+
+    torch.manual_seed(77)                         # the reference's loop, verbatim order of host draws
+    zw, zd = z2[:, :nw], z2[:, nw:]
+    d_sorted = importance_gumbel_softmax_sample(zd, temperature=q.temperature, offset=q.base, fixed_seed=False)
+    d = torch.zeros_like(d_sorted)
+    d[:, q.depth_order] = d_sorted
+    parts, s0 = [], 0
+    for w in q.width_list:
+        parts.append(gumbel_softmax_sample(zw[:, s0:s0 + w], temperature=q.temperature, offset=q.base,
+                                           force_width_non_zero=True, fixed_seed=False))
+        s0 += w
+    ref = torch.cat([torch.cat(parts, dim=1), d], dim=1)
+    assert torch.equal(got, ref)
+    assert float((hard_concrete(got)[1, :nw].reshape(1, -1) @ q._seg_maps(got.device)[0]).min()) >= 1.0   # no dead segment left
+    wgt = torch.randn_like(got)
+    (got * wgt).sum().backward()
+    (ref * wgt).sum().backward()
+    assert torch.allclose(z1.grad, z2.grad, rtol=0, atol=0)
+
+    # width_depth_normalize against the slice-assign loop
+    a = got.detach().clone().requires_grad_(True)
+    b = got.detach().clone().requires_grad_(True)
+    out = q.width_depth_normalize(a)
+    tmp = hard_concrete(b.clone())
+    for i, has_depth in enumerate(q.depth_list):
+        if has_depth != 0:
+            lo, hi = q.width_intervals[i]
+            di = q.depth_indices[i]
+            tmp[:, lo:hi] = b[:, lo:hi] * b[:, di:di + 1]
+    ref2 = tmp * torch.sqrt(q.template).detach()
+    assert torch.equal(out, ref2)
+    (out * wgt).sum().backward()
+    (ref2 * wgt).sum().backward()
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)    # the depth columns sum many products: order of summation only

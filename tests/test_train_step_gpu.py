@@ -140,3 +140,47 @@ def test_two_optimizer_steps_change_the_router(cuda):
     moved = sum(float((a - b.detach()).abs().sum()) for a, b in zip(before, step.trainable_parameters()))
     assert moved > 0
     assert qz.embedding.weight.grad is not None        # step 2 (pretrain=False) routes through the codebook
+
+
+def test_graphed_step_equals_eager_step(cuda):
+    """GraphedPrunerStep (both U-Net passes replayed from HIP graphs, chain rule closed eagerly) gives the eager step's
+    losses and router gradients, on two different batches through the same captured graphs."""
+    from diffusion_pruning_amd.train_step import GraphedPrunerStep, PrunerStep, synthetic_batch
+    cfg, unet, params, macs_model, hn, qz = build(cuda)
+    unet.to(cuda).freeze()
+    hn.to(cuda); qz.to(cuda)
+    hn.train(); qz.train()
+    eager = PrunerStep(unet, hn, qz)
+    eager.count_macs(16)
+    batches = [synthetic_batch(4, 16, cuda, seed=s, cross_dim=cfg.cross_attention_dim, text_dim=32) for s in (3, 4)]
+    ref = []
+    for i, b in enumerate(batches):
+        for p_ in eager.trainable_parameters():
+            p_.grad = None
+        torch.manual_seed(50 + i)
+        out = eager.step(b["noisy_latents"], b["timesteps"], b["encoder_hidden_states"], b["mpnet_embeddings"], b["target"],
+                         pretrain=(i == 0))
+        out["loss"].backward()
+        ref.append(({k: float(out[k]) for k in ("loss", "diff_loss", "distillation_loss", "block_loss", "resource_loss")},
+                    torch.cat([p_.grad.flatten().clone() for p_ in hn.parameters()])))
+    eager.remove_hooks()
+
+    graphed = GraphedPrunerStep(unet, hn, qz)
+    graphed.resource.p = eager.resource.p
+    graphed.capture(batches[0])
+    for i, b in enumerate(batches):
+        for p_ in graphed.trainable_parameters():
+            p_.grad = None
+        torch.manual_seed(50 + i)
+        out = graphed.step(b["noisy_latents"], b["timesteps"], b["encoder_hidden_states"], b["mpnet_embeddings"], b["target"],
+                           pretrain=(i == 0))
+        graphed.backward(out)
+        torch.cuda.synchronize()
+        vals, g_ref = ref[i]
+        # step 0 runs the same kernels as the eager step; step 1 (quantised, batch-shared hard code) runs the dense
+        # gate-multiply path where the eager step takes the compacted-weight path: bf16-level differences
+        tol = 1e-3 if i == 0 else 1e-2
+        for k, v in vals.items():
+            assert abs(float(out[k]) - v) <= tol * abs(v) + 1e-5, (i, k, float(out[k]), v)
+        g = torch.cat([p_.grad.flatten() for p_ in hn.parameters()])
+        assert rel_l2(g, g_ref) <= (1e-3 if i == 0 else 5e-2), (i, rel_l2(g, g_ref))

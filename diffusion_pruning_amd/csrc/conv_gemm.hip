@@ -21,7 +21,8 @@ __device__ unsigned long long g_stamps[4096 * 4];
 #define APTP_STAMP(i) do { } while (0)
 #endif
 #ifndef APTP_ABLATE
-#define APTP_ABLATE 0   // timing experiments only (tools/ablate_conv.sh): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no ds_read, 8 no barrier
+#define APTP_ABLATE 0   // timing experiments only (tools/ablate_conv.py): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no ds_read, 8 no barrier,
+                        // 32 no epilogue stores, 64 no residual / depth_in loads
 #endif
 
 namespace {
@@ -133,19 +134,23 @@ __device__ __forceinline__ void epilogue_quad(const KParams& p, int m, int b, in
     const float4 cc = *reinterpret_cast<const float4*>(p.corr + ((int64_t)(b % p.corr_B) * 9 + cls) * p.Nout + c);
     v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w;
   }
-  if (p.residual) {
+  if (p.residual && !(APTP_ABLATE & 64)) {
     const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldres + c);
     union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += (float)ru.e[r];
   }
-  if (p.depth) {
+  if (p.depth && !(APTP_ABLATE & 64)) {
     const float d = p.depth[b % p.depth_B];
     const uint2 rr = *reinterpret_cast<const uint2*>(p.depth_in + (int64_t)m * p.lddin + c);
     union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = (1.0f - d) * (float)ru.e[r] + d * v[r];
   }
+#if APTP_ABLATE & 32
+  asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  return;
+#endif
   if (p.out_f32) {
     float4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.ldy + c) = o;

@@ -104,6 +104,32 @@ def _live_index(mask: torch.Tensor, group: int) -> torch.Tensor:
     return (g[:, None] * group + torch.arange(group)[None, :]).flatten()
 
 
+class _CatSlot:
+    """One skip-concat buffer [B,H,W,Ch+Cs] of the up path (diffusers torch.cat([hidden, skip], dim=1)): the module that
+    produces `hidden` and the module that produces `skip` each write their result straight into their channel range, so
+    the concat costs no copy.  Allocated by whichever producer runs first (the skip, in the down path)."""
+
+    def __init__(self, c_hidden: int, c_skip: int):
+        self.ch, self.cs, self.buf = c_hidden, c_skip, None
+
+    def view(self, which: int, B: int, H: int, W: int, C: int, device) -> Optional[torch.Tensor]:
+        if C != (self.ch if which == 0 else self.cs):
+            return None
+        if self.buf is None:
+            self.buf = torch.empty(B, H, W, self.ch + self.cs, dtype=torch.bfloat16, device=device)
+        elif tuple(self.buf.shape[:3]) != (B, H, W) or self.buf.device != device:
+            return None
+        return self.buf[..., :self.ch] if which == 0 else self.buf[..., self.ch:]
+
+
+def _take_dst(mod, B: int, H: int, W: int, C: int, device) -> Optional[torch.Tensor]:
+    """destination view registered for this module's output by the model's forward (inference only), or None"""
+    d = mod.__dict__.pop("_out_dst", None)
+    if d is None or torch.is_grad_enabled():
+        return None
+    return d[0].view(d[1], B, H, W, C, device)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # ResNet blocks
 # ----------------------------------------------------------------------------------------------------------------
@@ -301,6 +327,7 @@ class ResnetBlock2DWidthGated(nn.Module):
 
     def forward(self, input_tensor: torch.Tensor, temb, scale: float = 1.0):
         x = _nhwc(input_tensor)
+        dst = _take_dst(self, x.shape[0], x.shape[1], x.shape[2], self.out_channels, x.device)
         if torch.is_grad_enabled() and self.conv1.weight.requires_grad:
             return self._forward_ft(x, temb)
         if self._needs_autograd(x):
@@ -324,7 +351,7 @@ class ResnetBlock2DWidthGated(nn.Module):
         dkw = {}
         if self.depth_gated and d_hard is None:
             dkw = dict(depth=d_vec, depth_in=x_in)
-        out = ops.conv_gemm(a2, pl["w2"], corr=pl["corr"], residual=sc, **dkw)
+        out = ops.conv_gemm(a2, pl["w2"], corr=pl["corr"], residual=sc, out=dst, **dkw)
         return _nchw(out)
 
     def _gate_dev(self, dev):
@@ -707,6 +734,7 @@ class Transformer2DModelWidthGated(nn.Module):
         if attention_mask is not None or encoder_attention_mask is not None:
             raise NotImplementedError("attention masks are not used on the APTP path (pruning_pipelines.py:796-802)")
         x = _nhwc(hidden_states)
+        dst = _take_dst(self, x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.device)
         if torch.is_grad_enabled() and self.proj_in.weight.requires_grad:
             if self.depth_gated and (self.dropped or self._depth_state()[0] == 0.0):
                 return self._ret(hidden_states, return_dict)
@@ -723,7 +751,7 @@ class Transformer2DModelWidthGated(nn.Module):
         P = H * W
         a = ops.groupnorm(x, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False)
         tok = a.reshape(B, P, C)
-        x_tok = x.reshape(B, P, C) if x.is_contiguous() else x.contiguous().reshape(B, P, C)
+        x_tok = x.reshape(B, P, C)      # a view also for a channel slice of a wider buffer (uniform pixel stride)
         h = ops.linear(tok, pl["proj_in"])
         # --- self attention
         n = ops.layernorm(h, pl["ln1_g"], pl["ln1_b"], 1e-5)
@@ -758,8 +786,8 @@ class Transformer2DModelWidthGated(nn.Module):
         dkw = {}
         if self.depth_gated and d_hard is None:
             dkw = dict(depth=d_vec, depth_in=x_tok)
-        out = ops.linear(h, pl["proj_out"], residual=x_tok, **dkw)
-        return self._ret(_nchw(out.reshape(B, H, W, C)), return_dict)
+        out = ops.linear(h, pl["proj_out"], residual=x_tok, out=None if dst is None else dst.reshape(B, P, C), **dkw)
+        return self._ret(_nchw(out.reshape(B, H, W, C) if dst is None else dst), return_dict)
 
     @staticmethod
     def _ret(t, return_dict):
@@ -823,6 +851,8 @@ class Downsample2D(nn.Module):
 
     def forward(self, hidden_states, scale: float = 1.0):
         x = _nhwc(hidden_states)
+        if torch.is_grad_enabled():
+            self.__dict__.pop("_out_dst", None)
         if self._pw is None or self._pw.w.device != x.device:
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
             self._pwb = None
@@ -832,7 +862,9 @@ class Downsample2D(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), stride=2, pad=1))
-        return _nchw(ops.conv_gemm(x, self._pw, stride=2, pad=1))
+        Ho, Wo = (x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1
+        dst = _take_dst(self, x.shape[0], Ho, Wo, self._pw.N, x.device)
+        return _nchw(ops.conv_gemm(x, self._pw, stride=2, pad=1, out=dst))
 
     def _get_bwd(self, dev):
         def get():
@@ -855,6 +887,8 @@ class Upsample2D(nn.Module):
 
     def forward(self, hidden_states, output_size=None, scale: float = 1.0):
         x = _nhwc(hidden_states)
+        if torch.is_grad_enabled():
+            self.__dict__.pop("_out_dst", None)
         if self._pw is None or self._pw.w.device != x.device:
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
             self._pwb = None
@@ -864,7 +898,8 @@ class Upsample2D(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), ups=1))
-        return _nchw(ops.conv_gemm(x, self._pw, ups=1))
+        dst = _take_dst(self, x.shape[0], 2 * x.shape[1], 2 * x.shape[2], self._pw.N, x.device)
+        return _nchw(ops.conv_gemm(x, self._pw, ups=1, out=dst))
 
     def _get_bwd(self, dev):
         def get():
@@ -1029,11 +1064,22 @@ class UpBlock2DWidthHalfDepthGated(CrossAttnUpBlock2DWidthHalfDepthGated):
                          resnet_groups, resnet_eps, with_attention=False)
 
 
+CAT_STATS = {"views": 0, "copies": 0}     # how the skip-concats of the forwards so far were realised (tests / tools)
+
+
 def _cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], dim=1) for channels_last activations, produced directly in NHWC memory."""
     A, Bn = _nhwc(a), _nhwc(b)
     if torch.is_grad_enabled() and (A.requires_grad or Bn.requires_grad):
         return _nchw(torch.cat([A, Bn], dim=3))
+    Ct = A.shape[3] + Bn.shape[3]
+    if (A.dtype == Bn.dtype and A.shape[:3] == Bn.shape[:3] and A.stride() == Bn.stride() and A.stride(3) == 1
+            and A.untyped_storage().data_ptr() == Bn.untyped_storage().data_ptr()
+            and Bn.storage_offset() == A.storage_offset() + A.shape[3] and ops._ld(A) == Ct):
+        # both halves were produced in place in one _CatSlot buffer: the concat is a view
+        CAT_STATS["views"] += 1
+        return _nchw(torch.as_strided(A, (A.shape[0], A.shape[1], A.shape[2], Ct), A.stride(), A.storage_offset()))
+    CAT_STATS["copies"] += 1
     out = torch.empty(A.shape[0], A.shape[1], A.shape[2], A.shape[3] + Bn.shape[3], dtype=A.dtype, device=A.device)
     out[..., :A.shape[3]].copy_(A)
     out[..., A.shape[3]:].copy_(Bn)
@@ -1369,6 +1415,37 @@ class UNet2DConditionModelGated(nn.Module):
         dev = encoder_hidden_states.device
         return self._project_context(encoder_hidden_states, self._batched_packs(dev), dev)
 
+    def _register_cat_slots(self, B, H, W, c_in, dev):
+        """Inference only: give every producer of a skip connection and every producer of an up-path hidden state the
+        channel range of the concat buffer its consumer (an up-block resnet, blocks.py:485-495 / diffusers
+        CrossAttnUpBlock2D.forward torch.cat) reads, so the 12 concats of a forward are views instead of copies.  A
+        producer that does not run its inference path (depth gate 0, autograd) simply ignores the slot and the consumer
+        falls back to the copying concat.  Returns the destination of conv_in's output."""
+        if torch.is_grad_enabled():
+            return None                                  # (_take_dst drops any stale registration under autograd)
+        skips = [None]                                   # conv_in is handled by the caller
+        for blk in self.down_blocks:
+            for i in range(len(blk.resnets)):
+                skips.append(blk.attentions[i] if blk.has_cross_attention else blk.resnets[i])
+            if blk.downsamplers is not None:
+                skips.append(blk.downsamplers[0])
+        prev = self.mid_block.resnets[-1]
+        conv_in_slot = None
+        for blk in self.up_blocks:
+            for i, resnet in enumerate(blk.resnets):
+                cs = resnet.skip_connection_dim
+                slot = _CatSlot(resnet.in_channels - cs, cs)
+                prev.__dict__["_out_dst"] = (slot, 0)
+                sk = skips.pop()
+                if sk is None:
+                    conv_in_slot = slot
+                else:
+                    sk.__dict__["_out_dst"] = (slot, 1)
+                prev = blk.attentions[i] if blk.has_cross_attention else resnet
+            if blk.upsamplers is not None:
+                prev = blk.upsamplers[0]
+        return None if conv_in_slot is None else conv_in_slot.view(1, B, H, W, c_in, dev)
+
     def _forward_ft(self, sample, timestep, encoder_hidden_states, return_dict):
         """Forward of the fine-tuning step: every parameter trainable (FineTuner, trainer.py:1529-1540, 1729)."""
         from . import autograd as AG
@@ -1469,7 +1546,8 @@ class UNet2DConditionModelGated(nn.Module):
         # 2. pre-process: conv_in on the channel-padded NHWC input
         x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
         x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
-        h = _nchw(ops.conv_gemm(x, misc["conv_in"]))
+        conv_in_dst = self._register_cat_slots(B, x.shape[1], x.shape[2], misc["conv_in"].N, dev)
+        h = _nchw(ops.conv_gemm(x, misc["conv_in"], out=conv_in_dst))
 
         # 3. down
         down_block_res_samples = (h,)

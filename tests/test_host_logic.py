@@ -57,6 +57,26 @@ def test_dense(tiny):
     assert rel_l2(run(model, O.ones_mask(cfg), sample, t, ehs), ref) <= TOL
 
 
+def test_skip_concats_are_views_without_autograd(tiny):
+    """the 12 torch.cat([hidden, skip]) of the up path (diffusers CrossAttnUpBlock2D.forward) are written in place by
+    their producers; a hard depth gate of 0 makes the skipped block's consumer fall back to the copying concat"""
+    from diffusion_pruning_amd import unet as U
+    cfg, model, params = tiny
+    sample, t, ehs = O.synthetic_inputs(cfg, 2, 16)
+    n_cat = sum(len(b.resnets) for b in model.up_blocks)
+    U.CAT_STATS.update(views=0, copies=0)
+    ref = O.unet_forward(params, cfg, sample, t, ehs)
+    assert rel_l2(run(model, O.ones_mask(cfg), sample, t, ehs), ref) <= TOL
+    assert U.CAT_STATS == {"views": n_cat, "copies": 0}
+    mask = O.ones_mask(cfg)
+    for d in mask["depth"]:
+        d.zero_()
+    U.CAT_STATS.update(views=0, copies=0)
+    ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
+    assert rel_l2(run(model, mask, sample, t, ehs), ref) <= TOL
+    assert U.CAT_STATS["views"] + U.CAT_STATS["copies"] == n_cat and U.CAT_STATS["copies"] > 0
+
+
 def test_half_mask_matches_gated_not_pruned(tiny):
     cfg, model, params = tiny
     sample, t, ehs = O.synthetic_inputs(cfg, 2, 16)

@@ -39,6 +39,9 @@ class ConvGemmParams(Structure):
         ("out_f32", c_int32), ("split_k", c_int32),
         ("workspace", c_void_p),
         ("tile", c_int32), ("order", c_int32),
+        ("rowstat_out", c_void_p), ("rowstat_slots", c_int32),
+        ("ln_stats", c_void_p), ("ln_slots", c_int32),
+        ("ln_colsum", c_void_p), ("ln_eps", c_float), ("ln_C", c_int32),
     ]
 
 
@@ -148,6 +151,7 @@ EXPORTS = [
     ("aptp_conv_gemm", c_int, [POINTER(ConvGemmParams), c_void_p]),
     ("aptp_conv_gemm_workspace_bytes", c_int64, [POINTER(ConvGemmParams)]),
     ("aptp_conv_gemm_suggest_split_k", c_int, [POINTER(ConvGemmParams)]),
+    ("aptp_conv_gemm_rowstat_slots", c_int, [POINTER(ConvGemmParams)]),
     ("aptp_groupnorm", c_int, [POINTER(GroupNormParams), c_void_p]),
     ("aptp_groupnorm_nchunk", c_int, [c_int]),
     ("aptp_groupnorm_workspace_bytes", c_int64, [POINTER(GroupNormParams)]),

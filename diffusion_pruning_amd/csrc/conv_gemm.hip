@@ -22,7 +22,7 @@ __device__ unsigned long long g_stamps[4096 * 4];
 #endif
 #ifndef APTP_ABLATE
 #define APTP_ABLATE 0   // timing experiments only (tools/ablate_conv.py): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no ds_read, 8 no barrier,
-                        // 32 no epilogue stores, 64 no residual / depth_in loads
+                        // 32 no epilogue stores, 64 no residual / depth_in loads, 128 no LayerNorm row-statistics fetch, 256 no ln_colsum loads
 #endif
 
 namespace {
@@ -48,6 +48,8 @@ struct KParams {
   int M, HW, Nout;          // Nout = logical output columns (N/2 for GEGLU)
   int64_t ws_ld;            // workspace row stride (floats)
   int order;                // workgroup -> tile order (decode_block): 0 legacy, 1 weight-major, 2 activation-major
+  float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
+  const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -95,9 +97,33 @@ __device__ __forceinline__ void decode_block(const KParams& p, int tiles_m, int 
 // For GEGLU `h` are the value columns at packed col n, `g` the gate columns at packed col n+16, and the logical
 // output column is (n/32)*16 + n%16.
 // ---------------------------------------------------------------------------------------------------------------
+// per-row context of the epilogue: sample index, border class (GroupNorm-beta correction) and, for a folded LayerNorm,
+// the row's mean / rstd finished from the producer's per-tile (sum, sumsq) partials
+struct RowCtx { int b, cls; float mean, rstd; };
+
 template <bool GEGLU>
-__device__ __forceinline__ void epilogue_quad(const KParams& p, int m, int b, int cls, int n, float h[4], float g[4]) {
+__device__ __forceinline__ void epilogue_quad(const KParams& p, int m, const RowCtx& rc, int n, float h[4], float g[4], float st[2]) {
+  const int b = rc.b, cls = rc.cls;
   float v[4];
+  if (p.ln_stats) {
+    // y = LN(x) W^T with gamma folded into W:  rstd * (x W'^T - mean * colsum(W')) ; the beta term sits in `bias`
+#if APTP_ABLATE & 256
+    const float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
+    const float4 cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+#endif
+    h[0] = rc.rstd * (h[0] - rc.mean * cs.x); h[1] = rc.rstd * (h[1] - rc.mean * cs.y);
+    h[2] = rc.rstd * (h[2] - rc.mean * cs.z); h[3] = rc.rstd * (h[3] - rc.mean * cs.w);
+    if (GEGLU) {
+#if APTP_ABLATE & 256
+      const float4 cg = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
+      const float4 cg = *reinterpret_cast<const float4*>(p.ln_colsum + n + 16);
+#endif
+      g[0] = rc.rstd * (g[0] - rc.mean * cg.x); g[1] = rc.rstd * (g[1] - rc.mean * cg.y);
+      g[2] = rc.rstd * (g[2] - rc.mean * cg.z); g[3] = rc.rstd * (g[3] - rc.mean * cg.w);
+    }
+  }
   if (p.bias) {
     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
     h[0] += bb.x; h[1] += bb.y; h[2] += bb.z; h[3] += bb.w;
@@ -155,20 +181,159 @@ __device__ __forceinline__ void epilogue_quad(const KParams& p, int m, int b, in
     float4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.ldy + c) = o;
   } else {
-    uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p.y) + (int64_t)m * p.ldy + c) = o;
+    union { uint2 u; __bf16 e[4]; } o;
+    o.u.x = pack_bf16x2(v[0], v[1]); o.u.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p.y) + (int64_t)m * p.ldy + c) = o.u;
+    if (p.rstat_out) {          // statistics of the values as stored (bf16-rounded): what the consumer will read
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float f = (float)o.e[r]; st[0] += f; st[1] += f * f; }
+    }
   }
 }
 
-__device__ __forceinline__ void row_info(const KParams& p, int m, int& b, int& cls) {
-  b = m / p.HW;
-  cls = 4;
+__device__ __forceinline__ void row_info(const KParams& p, int m, RowCtx& rc) {
+  rc.b = m / p.HW;
+  rc.cls = 4;
+  rc.mean = 0.f; rc.rstd = 1.f;
   if (p.corr) {
-    const int rem = m - b * p.HW;
+    const int rem = m - rc.b * p.HW;
     const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-    const int rc = oy == 0 ? 0 : (oy == p.Hout - 1 ? 2 : 1);
+    const int rr = oy == 0 ? 0 : (oy == p.Hout - 1 ? 2 : 1);
     const int cc = ox == 0 ? 0 : (ox == p.Wout - 1 ? 2 : 1);
-    cls = rc * 3 + cc;
+    rc.cls = rr * 3 + cc;
+  }
+}
+
+__device__ __forceinline__ void ln_finish(const KParams& p, float a, float a2, RowCtx& rc) {
+  const float mean = a * p.ln_invC;
+  float var = a2 * p.ln_invC - mean * mean;
+  var = var < 0.f ? 0.f : var;
+  rc.mean = mean;
+  rc.rstd = rsqrtf(var + p.ln_eps);
+}
+
+// Epilogue of one workgroup tile from the MFMA accumulators:
+//   acc[i][j][r] = out[m = m0 + wm*WTM + i*16 + (lane&15)][n = n0 + wn*WTN + j*16 + (lane>>4)*4 + r]
+// With rstat_out, each wave also emits its rows' (sum, sumsq) over the columns it owns into slot tn*WN + wn: the four
+// lanes that share a row (lane>>4 = 0..3) fold their partial sums with two cross-lane adds.
+// Folded LayerNorm: mean / rstd of this lane's MF rows from the producer's partials [slots][M] (sum, sumsq).
+// Two halves, both in the kernel PROLOGUE: ln_rows_issue() at the very top requests the first 16 slots (the four lanes that
+// share a row split the slots, slot = fq, fq+4, ...; all MF rows per lane => 4*MF independent 8-byte loads), and
+// ln_rows_finish(), called after the first operand tiles have been requested, folds them.  Its wait coincides with the
+// wait for operand tile 0, so the statistics cost no extra memory round trip (in the epilogue, or requested after the
+// operand tiles, they cost every workgroup one loaded L2 round trip: +3..6 us per launch on the GEGLU projections).
+// More than 16 slots (a 1280-wide producer on 64-wide tiles) take further rounds inside ln_rows_finish.  Fixed fold
+// order: deterministic.
+template <int MF>
+struct LnRaw { float2 v[4][MF]; int mr[MF]; };
+
+template <int MF, int WTM>
+__device__ __forceinline__ void ln_rows_issue(const KParams& p, int m0, int wm, int lane, LnRaw<MF>& raw) {
+  if (!p.ln_stats || p.split_k > 1 || (APTP_ABLATE & 128)) return;      // (split-K: the reducer finishes the rows itself)
+  const int frow = lane & 15, fq = lane >> 4;
+  const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    raw.mr[i] = m < p.M ? m : p.M - 1;
+  }
+  // (these short-K launches are bound by the vector-memory instruction rate, so rounds with no live slot are skipped
+  // by a wave-uniform branch: MF * ceil(slots/4) load instructions per wave, every lane a distinct (row, slot))
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (u * 4 < p.ln_slots) {
+      const int sl = u * 4 + fq;
+      const int64_t row0 = (int64_t)(sl < p.ln_slots ? sl : 0) * p.M;
+#pragma unroll
+      for (int i = 0; i < MF; ++i) raw.v[u][i] = sp[row0 + raw.mr[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < MF; ++i) raw.v[u][i] = make_float2(0.f, 0.f);
+    }
+  }
+  asm volatile("" ::: "memory");      // keep the requests here, ahead of the address generation and the operand DMA
+}
+
+template <int MF>
+__device__ __forceinline__ void ln_rows_finish(const KParams& p, int lane, const LnRaw<MF>& raw, float (&ln_mean)[MF], float (&ln_rstd)[MF]) {
+  if (!p.ln_stats || p.split_k > 1 || (APTP_ABLATE & 128)) return;
+  const int fq = lane >> 4;
+  const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
+  float lna[MF], lna2[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) { lna[i] = 0.f; lna2[i] = 0.f; }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool ok = u * 4 + fq < p.ln_slots;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) { lna[i] += ok ? raw.v[u][i].x : 0.f; lna2[i] += ok ? raw.v[u][i].y : 0.f; }
+  }
+  for (int base = 16; base < p.ln_slots; base += 16) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (base + u * 4 < p.ln_slots) {
+        const int sl = base + u * 4 + fq;
+        const bool ok = sl < p.ln_slots;
+        const int64_t row0 = (int64_t)(ok ? sl : 0) * p.M;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          const float2 t = sp[row0 + raw.mr[i]];
+          lna[i] += ok ? t.x : 0.f; lna2[i] += ok ? t.y : 0.f;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    lna[i] += __shfl_xor(lna[i], 16); lna2[i] += __shfl_xor(lna2[i], 16);
+    lna[i] += __shfl_xor(lna[i], 32); lna2[i] += __shfl_xor(lna2[i], 32);
+    RowCtx rc;
+    ln_finish(p, lna[i], lna2[i], rc);
+    ln_mean[i] = rc.mean; ln_rstd[i] = rc.rstd;
+  }
+}
+
+template <int MF, int NF, int WTM, int WTN, int WN>
+__device__ __forceinline__ void tile_epilogue(const KParams& p, f32x4 (&acc)[MF][NF], int m0, int n0, int tn, int wm, int wn, int lane,
+                                              const float (&ln_mean)[MF], const float (&ln_rstd)[MF]) {
+  const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    if (m >= p.M) continue;
+    RowCtx rc;
+    row_info(p, m, rc);
+    rc.mean = ln_mean[i]; rc.rstd = ln_rstd[i];
+    float st[2] = {0.f, 0.f};
+    if (p.act == APTP_ACT_GEGLU) {
+      if constexpr (NF % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NF; j += 2) {
+          const int n = n0 + wn * WTN + j * 16 + fq * 4;
+          if (n >= p.N) continue;
+          float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+          epilogue_quad<true>(p, m, rc, n, h, g, st);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        epilogue_quad<false>(p, m, rc, n, h, h, st);
+      }
+    }
+    if (p.rstat_out) {
+      // lanes l, l^16, l^32, l^48 hold the same row (and took the same branches above)
+      st[0] += __shfl_xor(st[0], 16); st[1] += __shfl_xor(st[1], 16);
+      st[0] += __shfl_xor(st[0], 32); st[1] += __shfl_xor(st[1], 32);
+      if (fq == 0) {
+        float2 o; o.x = st[0]; o.y = st[1];
+        reinterpret_cast<float2*>(p.rstat_out)[(int64_t)(tn * WN + wn) * p.M + m] = o;   // [slots][M]: 16 rows = 128 B
+      }
+    }
   }
 }
 
@@ -196,6 +361,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
   const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+  LnRaw<MF> ln_raw;
+  ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw);
 
   // ---- per-thread staging coordinates -------------------------------------------------------------------------
   // Operands are fetched with raw buffer loads: an out-of-range offset returns zeros, which implements the conv
@@ -312,8 +479,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   // ---- main loop: one barrier per K-step, loads for step t+1 in flight during the MFMAs of step t ----------------
   // (the prefetch of the step past the end is predicated off and its zero tile is stored but never read, which keeps
   // the loop body branch-free so the staging registers stay in VGPRs)
+  float ln_mean[MF], ln_rstd[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) { ln_mean[i] = 0.f; ln_rstd[i] = 1.f; }
   {
     load_tile(kt_begin < kt_end);
+    ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
     store_tile(0);
     __syncthreads();
     int buf = 0;
@@ -344,33 +515,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < MF; ++i) {
-    const int m = m0 + wm * WTM + i * 16 + frow;
-    if (m >= p.M) continue;
-    int b, cls;
-    row_info(p, m, b, cls);
-    if (p.act == APTP_ACT_GEGLU) {
-      if constexpr (NF % 2 == 0) {
-#pragma unroll
-        for (int j = 0; j < NF; j += 2) {
-          const int n = n0 + wn * WTN + j * 16 + fq * 4;
-          if (n >= p.N) continue;
-          float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-          epilogue_quad<true>(p, m, b, cls, n, h, g);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + fq * 4;
-        if (n >= p.N) continue;
-        float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        epilogue_quad<false>(p, m, b, cls, n, h, h);
-      }
-    }
-  }
+  tile_epilogue<MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -416,6 +561,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   const int m0 = tm * BM, n0 = tn * BN;
   const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
   const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+  LnRaw<MF> ln_raw;
+  ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw);
 
   const int rowbase = tid >> 3;
   const int schunk = (tid & 7) ^ ((rowbase >> 1) & 7);      // source chunk that lands in this lane's LDS slot
@@ -558,6 +705,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     }
   };
 
+  float ln_mean[MF], ln_rstd[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) { ln_mean[i] = 0.f; ln_rstd[i] = 1.f; }
   if constexpr (PP) {
     // Ping-pong schedule (8 waves = two groups of four; waves w and w+4 share a SIMD).  Every K-step is two slots
     // separated by workgroup barriers: in slot L a wave issues its share of the LDS-DMA for tile k+D, in slot C it
@@ -582,6 +732,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     if (n > 0) {
       const int pre = n < D ? n : D;
       for (int t = 0; t < pre; ++t) issue_tile(t);
+      ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
       if (pre == D) {
         if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
@@ -637,6 +788,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   if constexpr (STAGES == 2) {
     if (kt_begin < kt_end) {
       issue_tile(0);
+      ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
       __syncthreads();                       // (the compiler drains vmcnt(0) for the LDS-DMA before the barrier)
       int buf = 0;
       for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -669,6 +821,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     if (n > 0) {
       const int pre = n < D ? n : D;
       for (int t = 0; t < pre; ++t) issue_tile(t);
+      ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
       if (pre == D) {   // tile 0 landed, D-1 tiles still in flight
         if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
@@ -727,33 +880,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < MF; ++i) {
-    const int m = m0 + wm * WTM + i * 16 + frow;
-    if (m >= p.M) continue;
-    int b, cls;
-    row_info(p, m, b, cls);
-    if (p.act == APTP_ACT_GEGLU) {
-      if constexpr (NF % 2 == 0) {
-#pragma unroll
-        for (int j = 0; j < NF; j += 2) {
-          const int n = n0 + wn * WTN + j * 16 + fq * 4;
-          if (n >= p.N) continue;
-          float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-          epilogue_quad<true>(p, m, b, cls, n, h, g);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + fq * 4;
-        if (n >= p.N) continue;
-        float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        epilogue_quad<false>(p, m, b, cls, n, h, h);
-      }
-    }
-  }
+  tile_epilogue<MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd);
 }
 
 // split-K reducer + epilogue: one thread per (row, 4 packed columns)
@@ -776,21 +903,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
       g[0] += c.x; g[1] += c.y; g[2] += c.z; g[3] += c.w;
     }
   }
-  int b, cls;
-  row_info(p, m, b, cls);
-  if (p.act == APTP_ACT_GEGLU) epilogue_quad<true>(p, m, b, cls, n, h, g);
-  else epilogue_quad<false>(p, m, b, cls, n, h, h);
+  RowCtx rc;
+  row_info(p, m, rc);
+  if (p.ln_stats) {
+    const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
+    float a = 0.f, a2 = 0.f;
+    for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 t = sp[(int64_t)sl * p.M + m]; a += t.x; a2 += t.y; }
+    ln_finish(p, a, a2, rc);
+  }
+  float st[2] = {0.f, 0.f};     // (row statistics are only emitted by the un-split kernel: checked on the host)
+  if (p.act == APTP_ACT_GEGLU) epilogue_quad<true>(p, m, rc, n, h, g, st);
+  else epilogue_quad<false>(p, m, rc, n, h, h, st);
 }
 
-struct TileCfg { int bm, bn; };
-const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},
-                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},    // 7..12: LDS-DMA, 2 stages
-                          {128, 128}, {128, 160}, {64, 128}, {64, 160}, {128, 64}, {64, 64},    // 13..18: LDS-DMA, 3 stages
-                          {128, 160}, {256, 160}, {128, 128}, {256, 128},                       // 19..22: LDS-DMA, 8 waves
-                          {64, 160}, {64, 128}, {64, 64}, {128, 64}, {128, 128},                // 23..27: LDS-DMA, 4 stages
-                          {128, 160}, {128, 160}, {128, 128}, {128, 128}, {256, 128},           // 28..32: 8 waves, 3/4-stage ring
-                          {128, 160}, {128, 160}, {128, 128}, {128, 128}, {64, 160}, {64, 128}, // 33..38: 8 waves, ping-pong
-                          {64, 160}, {128, 64}, {256, 128}, {128, 256}};                        // 39..42
+struct TileCfg { int bm, bn, wn; };   // tile extents and the wave grid's N extent (launch table below)
+const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 2}, {128, 160, 2}, {64, 128, 2}, {64, 160, 2}, {128, 64, 2}, {64, 64, 2},
+                          {128, 128, 2}, {128, 160, 2}, {64, 128, 2}, {64, 160, 2}, {128, 64, 2}, {64, 64, 2},    // 7..12: LDS-DMA, 2 stages
+                          {128, 128, 2}, {128, 160, 2}, {64, 128, 2}, {64, 160, 2}, {128, 64, 2}, {64, 64, 2},    // 13..18: LDS-DMA, 3 stages
+                          {128, 160, 2}, {256, 160, 2}, {128, 128, 4}, {256, 128, 2},                             // 19..22: LDS-DMA, 8 waves
+                          {64, 160, 2}, {64, 128, 2}, {64, 64, 2}, {128, 64, 2}, {128, 128, 2},                   // 23..27: LDS-DMA, 4 stages
+                          {128, 160, 2}, {128, 160, 2}, {128, 128, 4}, {128, 128, 4}, {256, 128, 2},              // 28..32: 8 waves, 3/4-stage ring
+                          {128, 160, 2}, {128, 160, 2}, {128, 128, 4}, {128, 128, 4}, {64, 160, 2}, {64, 128, 4}, // 33..38: 8 waves, ping-pong
+                          {64, 160, 2}, {128, 64, 2}, {256, 128, 2}, {128, 256, 4}};                              // 39..42
 constexpr int kNumTiles = 43;
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
@@ -859,6 +993,14 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   } else {
     k.order = p->order - 1;   // 1 legacy, 2 weight-major, 3 activation-major
   }
+  k.rstat_out = p->rowstat_out; k.rstat_slots = p->rowstat_slots;
+  k.ln_stats = p->ln_stats; k.ln_slots = p->ln_slots; k.ln_colsum = p->ln_colsum; k.ln_eps = p->ln_eps;
+  k.ln_invC = p->ln_C > 0 ? 1.0f / (float)p->ln_C : 0.f;
+  APTP_CHECK(!p->rowstat_out || (!geglu && !p->out_f32 && ((uintptr_t)p->rowstat_out % 8) == 0),
+             "conv_gemm: rowstat_out needs a bf16, non-GEGLU output and an 8-byte aligned buffer");
+  APTP_CHECK(!p->ln_stats || (p->ln_colsum && p->ln_slots > 0 && p->ln_C > 0 && p->KH == 1 && p->KW == 1 &&
+                              ((uintptr_t)p->ln_stats % 8) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
+             "conv_gemm: folded LayerNorm needs ln_colsum [N], ln_slots > 0, ln_C > 0 and a 1x1 filter");
   const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * 2;
   const int64_t wb = (int64_t)p->N * k.Ktot * 2;
   APTP_CHECK(xb < (1ll << 31) && wb < (1ll << 31), "conv_gemm: operand larger than 2 GiB");
@@ -909,6 +1051,13 @@ extern "C" int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p) {
   return (int64_t)p->split_k * p->B * p->Hout * p->Wout * p->N * (int64_t)sizeof(float);
 }
 
+extern "C" int aptp_conv_gemm_rowstat_slots(const AptpConvGemmParams* p) {
+  if (!p) return 0;
+  const int t = pick_tile(p, p->B * p->Hout * p->Wout);
+  if (t <= 0 || t >= kNumTiles) return 0;
+  return ((p->N + kTiles[t].bn - 1) / kTiles[t].bn) * kTiles[t].wn;
+}
+
 extern "C" int aptp_conv_gemm_suggest_split_k(const AptpConvGemmParams* p) {
   if (!p) return 1;
   const int M = p->B * p->Hout * p->Wout;
@@ -935,6 +1084,14 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     // the LDS-DMA variants stream padding lanes from an 8 KiB zero page that must cover one channel row
     aptp_set_error("conv_gemm: LDS-DMA tiles need Cin <= 4032 (got cin_pad %d)", p->cin_pad);
     return APTP_EINVAL;
+  }
+  if (k.rstat_out) {
+    const int slots = ((k.N + kTiles[t].bn - 1) / kTiles[t].bn) * kTiles[t].wn;
+    if (k.split_k != 1 || k.rstat_slots != slots) {
+      aptp_set_error("conv_gemm: rowstat_out needs split_k == 1 and rowstat_slots == aptp_conv_gemm_rowstat_slots() (%d), got split_k %d, slots %d",
+                     slots, k.split_k, k.rstat_slots);
+      return APTP_EINVAL;
+    }
   }
   if (k.act == APTP_ACT_GEGLU && (kTiles[t].bn == 160)) {
     aptp_set_error("conv_gemm: GEGLU cannot use a 160-wide tile");

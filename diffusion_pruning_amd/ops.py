@@ -64,6 +64,7 @@ class PackedWeight:
     KH: int
     KW: int
     geglu: bool = False
+    ln_colsum: Optional[torch.Tensor] = None   # fp32 [N]: row sums of the bf16 weights when a LayerNorm is folded in
 
     @property
     def cin_pad(self) -> int:
@@ -76,20 +77,30 @@ def round_up(v: int, m: int) -> int:
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out_idx: Optional[torch.Tensor] = None,
                 in_idx: Optional[torch.Tensor] = None, n_pad_to: int = 8, cin_pad_to: int = 8,
-                geglu: bool = False, device=None) -> PackedWeight:
+                geglu: bool = False, device=None, ln_gamma: Optional[torch.Tensor] = None,
+                ln_beta: Optional[torch.Tensor] = None) -> PackedWeight:
     """Pack an OIHW conv weight (or [out,in] linear weight) for aptp_conv_gemm.
 
     out_idx / in_idx: live output / input channel indices (architecture-code compaction; the reference's
     prune() slicing, blocks.py:436-463, 159-177, 55-64, 126).  Output rows and input columns are zero-padded to
     multiples of n_pad_to / cin_pad_to (pad rows produce exact zeros), then Cin to a multiple of 64.
     geglu: interleave the two halves of a GEGLU projection in [16 value | 16 gate] row blocks so the epilogue finds
-    h and g of one hidden unit in the same lane."""
+    h and g of one hidden unit in the same lane.
+    ln_gamma / ln_beta: fold the LayerNorm that precedes this linear layer into it (include/aptp_hip.h, ln_stats):
+    w' = w * gamma, bias' = bias + w @ beta; PackedWeight.ln_colsum = row sums of the bf16-rounded w'."""
     if w.dim() == 2:
         w = w[:, :, None, None]
     device = device or w.device
     w = w.to(device=device, dtype=torch.float32)
     if bias is not None:
         bias = bias.to(device=device, dtype=torch.float32)
+    if ln_gamma is not None:
+        assert w.shape[2] == 1 and w.shape[3] == 1 and in_idx is None, "a LayerNorm folds into a linear layer over all its channels"
+        ga = ln_gamma.to(device=device, dtype=torch.float32)
+        be = ln_beta.to(device=device, dtype=torch.float32)
+        shift = w[:, :, 0, 0] @ be
+        bias = shift if bias is None else bias + shift
+        w = w * ga[None, :, None, None]
     if geglu:
         inner = w.shape[0] // 2
         wh, wg = w[:inner], w[inner:]
@@ -135,7 +146,8 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out_idx
     cin_pad = round_up(cin_live, BK)
     packed = torch.zeros(N, KH * KW, cin_pad, dtype=torch.bfloat16, device=device)
     packed[:, :, :Cin] = w.permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(torch.bfloat16)
-    return PackedWeight(packed.contiguous(), None if bias is None else bias.contiguous(), N, cin_live, KH, KW, geglu)
+    colsum = packed.float().sum(dim=(1, 2)).contiguous() if ln_gamma is not None else None
+    return PackedWeight(packed.contiguous(), None if bias is None else bias.contiguous(), N, cin_live, KH, KW, geglu, colsum)
 
 
 _ws_cache = {}
@@ -178,8 +190,12 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               colgate: Optional[torch.Tensor] = None, gate_group: int = 0, act: int = ACT_NONE,
               corr: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
-              out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0) -> torch.Tensor:
-    """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites."""
+              out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0,
+              rowstats: bool = False, ln=None):
+    """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites.
+    rowstats: also emit the per-row (sum, sumsq) partials of y a following folded LayerNorm needs; returns (y, stats)
+    with stats fp32 [slots, M, 2], or (y, None) when this launch is split along K (the caller then normalises with
+    ops.layernorm).  ln = (stats, eps): x is the un-normalised input of a LayerNorm folded into pw (pack_weight ln_gamma)."""
     lib = _lib.load()
     _check_act(x, "conv_gemm x")
     B, Hin, Win, Cx = x.shape
@@ -243,6 +259,21 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if split_k is None:
         split_k = lib.aptp_conv_gemm_suggest_split_k(ctypes.byref(p))
     p.split_k = max(1, int(split_k))
+    stats = None
+    if rowstats and p.split_k == 1:
+        slots = lib.aptp_conv_gemm_rowstat_slots(ctypes.byref(p))
+        stats = torch.empty(slots, B * Hout * Wout, 2, dtype=torch.float32, device=x.device)
+        p.rowstat_out, p.rowstat_slots = stats.data_ptr(), slots
+    if ln is not None:
+        ln_stats, ln_eps = ln
+        if pw.ln_colsum is None:
+            raise ValueError("conv_gemm: ln= needs weights packed with ln_gamma / ln_beta")
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.shape[1] == B * Hout * Wout \
+            and ln_stats.shape[2] == 2
+        p.ln_stats, p.ln_slots, p.ln_colsum = ln_stats.data_ptr(), ln_stats.shape[0], pw.ln_colsum.data_ptr()
+        p.ln_eps, p.ln_C = ln_eps, Cx
+    elif pw.ln_colsum is not None:
+        raise ValueError("conv_gemm: weights with a folded LayerNorm need ln=(stats, eps)")
     ws = None
     if p.split_k > 1:
         ws = _workspace(lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(p)), x.device)
@@ -250,8 +281,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     _lib.check(lib.aptp_conv_gemm(ctypes.byref(p), _stream()), "aptp_conv_gemm")
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * pw.KH * pw.KW * pw.Cin,
-                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws)})
-    return out
+                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln)})
+    return (out, stats) if rowstats else out
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
@@ -262,6 +293,8 @@ def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
         if kw.get(k) is not None:
             kw[k] = kw[k].unsqueeze(2)
     y = conv_gemm(x.unsqueeze(2), pw, pad=0, out=None if out is None else out.unsqueeze(2), **kw)
+    if "rowstats" in kw:
+        return (y[0].squeeze(2), y[1]) if kw["rowstats"] else (y.squeeze(2), None)
     return y.squeeze(2)
 
 

@@ -547,8 +547,14 @@ class Transformer2DModelWidthGated(nn.Module):
                 wq, wk, wv = wq[live], wk[live], wv[live]
             if not attn.is_cross:
                 pl[name + "_qkv"] = ops.pack_weight(torch.cat([wq, wk, wv], 0), None, device=dev)
+                pl["a1_qkv_ln_make"] = (lambda attn=attn, live=live: ops.pack_weight(
+                    torch.cat([_f32(t.weight) if live is None else _f32(t.weight)[live] for t in (attn.to_q, attn.to_k, attn.to_v)], 0),
+                    None, device=dev, ln_gamma=pl["ln1_g"], ln_beta=pl["ln1_b"]))
             else:
                 pl[name + "_q"] = ops.pack_weight(wq, None, device=dev)
+                pl["a2_q_ln_make"] = (lambda attn=attn, live=live: ops.pack_weight(
+                    _f32(attn.to_q.weight) if live is None else _f32(attn.to_q.weight)[live], None, device=dev,
+                    ln_gamma=pl["ln2_g"], ln_beta=pl["ln2_b"]))
                 pl[name + "_kv_w"] = torch.cat([wk, wv], 0)          # batched across layers by the model
             pl[name + "_o"] = ops.pack_weight(attn.to_out[0].weight.detach(), attn.to_out[0].bias.detach(),
                                               in_idx=live, device=dev)
@@ -561,6 +567,9 @@ class Transformer2DModelWidthGated(nn.Module):
         live = _live_index(mask, chunk) if compact else None
         pl["ff_compact"], pl["ff_dense_gate"] = compact, mask is None
         pl["ff1"] = ops.pack_weight(geglu.proj.weight.detach(), geglu.proj.bias.detach(), out_idx=live, geglu=True, device=dev)
+        pl["ff1_ln_make"] = (lambda geglu=geglu, live=live: ops.pack_weight(
+            geglu.proj.weight.detach(), geglu.proj.bias.detach(), out_idx=live, geglu=True, device=dev,
+            ln_gamma=pl["ln3_g"], ln_beta=pl["ln3_b"]))
         inner_pad = pl["ff1"].N // 2
         pl["ff2"] = ops.pack_weight(lin2.weight.detach(), lin2.bias.detach(), in_idx=live, cin_pad_to=16, device=dev)
         assert pl["ff2"].Cin == inner_pad, (pl["ff2"].Cin, inner_pad)
@@ -752,35 +761,34 @@ class Transformer2DModelWidthGated(nn.Module):
         a = ops.groupnorm(x, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False)
         tok = a.reshape(B, P, C)
         x_tok = x.reshape(B, P, C)      # a view also for a channel slice of a wider buffer (uniform pixel stride)
-        h = ops.linear(tok, pl["proj_in"])
+        # The three LayerNorms are folded into their neighbours: the GEMM that produces the residual stream emits per-row
+        # (sum, sumsq) partials, the GEMM that consumes LN(h) reads h with gamma folded into its weights (_ln_linear).
+        h, st = ops.linear(tok, pl["proj_in"], rowstats=FOLD_LN)
         # --- self attention
-        n = ops.layernorm(h, pl["ln1_g"], pl["ln1_b"], 1e-5)
         hl = pl["a1_heads"]
         gkw = {}
         if pl["a1_dense_gate"]:
             gkw = dict(colgate=self._gate(tb.attn1.gate, dev, 3), gate_group=64)
-        qkv = ops.linear(n, pl["a1_qkv"], **gkw)
+        qkv = self._ln_linear(pl, h, st, 1, "a1_qkv", **gkw)
         w = hl * 64
         o = ops.attention(qkv[..., :w], qkv[..., w:2 * w], qkv[..., 2 * w:3 * w], hl)
-        h = ops.linear(o, pl["a1_o"], residual=h)
+        h, st = ops.linear(o, pl["a1_o"], residual=h, rowstats=FOLD_LN)
         # --- cross attention
-        n = ops.layernorm(h, pl["ln2_g"], pl["ln2_b"], 1e-5)
         hl = pl["a2_heads"]
         w = hl * 64
         gkw = {}
         if pl["a2_dense_gate"]:
             gkw = dict(colgate=self._gate(tb.attn2.gate, dev), gate_group=64)
-        q = ops.linear(n, pl["a2_q"], **gkw)
+        q = self._ln_linear(pl, h, st, 2, "a2_q", **gkw)
         kv = self._ctx_kv(encoder_hidden_states, pl, tb, dev)
         o = ops.attention(q, kv[..., :w], kv[..., w:2 * w], hl)
-        h = ops.linear(o, pl["a2_o"], residual=h)
+        h, st = ops.linear(o, pl["a2_o"], residual=h, rowstats=FOLD_LN)
         # --- feed-forward
-        n = ops.layernorm(h, pl["ln3_g"], pl["ln3_b"], 1e-5)
         gkw = {}
         if pl["ff_dense_gate"]:
             geglu = tb.ff.net[0]
             gkw = dict(colgate=self._gate(geglu.gate, dev), gate_group=geglu.dim_out // geglu.gate.width)
-        f = ops.linear(n, pl["ff1"], **gkw)
+        f = self._ln_linear(pl, h, st, 3, "ff1", **gkw)
         h = ops.linear(f, pl["ff2"], residual=h)
         # --- proj_out + residual (+ depth lerp)
         dkw = {}
@@ -788,6 +796,18 @@ class Transformer2DModelWidthGated(nn.Module):
             dkw = dict(depth=d_vec, depth_in=x_tok)
         out = ops.linear(h, pl["proj_out"], residual=x_tok, out=None if dst is None else dst.reshape(B, P, C), **dkw)
         return self._ret(_nchw(out.reshape(B, H, W, C) if dst is None else dst), return_dict)
+
+    @staticmethod
+    def _ln_linear(pl, h, st, idx, name, **kw):
+        """linear(LayerNorm_idx(h)) (blocks.py:782-785,808-813,821-823): folded into ONE launch when the producer of h
+        emitted row statistics, otherwise the stand-alone LayerNorm kernel followed by the plain GEMM"""
+        if st is None:
+            n = ops.layernorm(h, pl[f"ln{idx}_g"], pl[f"ln{idx}_b"], 1e-5)
+            return ops.linear(n, pl[name], **kw)
+        pw = pl.get(name + "_ln")
+        if pw is None:
+            pw = pl[name + "_ln"] = pl[name + "_ln_make"]()
+        return ops.linear(h, pw, ln=(st, 1e-5), **kw)
 
     @staticmethod
     def _ret(t, return_dict):
@@ -1064,6 +1084,8 @@ class UpBlock2DWidthHalfDepthGated(CrossAttnUpBlock2DWidthHalfDepthGated):
                          resnet_groups, resnet_eps, with_attention=False)
 
 
+# APTP_FOLD_LN=0 keeps the three LayerNorms of a transformer block as stand-alone kernels (A/B timing, debugging)
+FOLD_LN = os.environ.get("APTP_FOLD_LN", "1") != "0"
 CAT_STATS = {"views": 0, "copies": 0}     # how the skip-concats of the forwards so far were realised (tests / tools)
 
 

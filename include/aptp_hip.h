@@ -85,6 +85,21 @@ typedef struct {
   int32_t tile;         /* 0 = auto; otherwise APTP_TILE_* (testing / tuning) */
   int32_t order;        /* workgroup -> tile order over the 8 XCDs: 0 = auto (partition the larger operand), 1 = legacy
                          * (N-tile fastest), 2 = weight-major, 3 = activation-major (testing / tuning) */
+  /* LayerNorm folded into the neighbouring GEMMs (nn.LayerNorm norm1/norm2/norm3 of BasicTransformerBlock,
+   * blocks.py:782,808-810,821; inference path).  The GEMM that PRODUCES the normalised tensor (proj_in, to_out with its
+   * residual) also emits, per output row, fp32 (sum, sumsq) partials of the bf16 values it stores, one per (N-tile, wave
+   * column): rowstat_out [rowstat_slots, M, 2], rowstat_slots = aptp_conv_gemm_rowstat_slots(); needs split_k == 1, a bf16
+   * non-GEGLU output.  The GEMM that CONSUMES LayerNorm(x) reads x itself with gamma folded into its packed weights
+   * (w' = w * gamma) and finishes the normalisation in its epilogue, before bias:
+   *     v = rstd[m] * (acc[m, n] - mean[m] * ln_colsum[n]),   mean/rstd from ln_stats [ln_slots, M, 2] over ln_C channels,
+   * ln_colsum[n] = sum_k bf16(w'[n, k]) (fp32), and the caller adds sum_k beta[k] w[n, k] to bias[n]. */
+  float* rowstat_out;
+  int32_t rowstat_slots;
+  const float* ln_stats;
+  int32_t ln_slots;
+  const float* ln_colsum;
+  float ln_eps;
+  int32_t ln_C;
 } AptpConvGemmParams;
 
 enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TILE_64x128 = 3, APTP_TILE_64x160 = 4,
@@ -110,6 +125,8 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);
+/* number of row-statistics slots a launch of this problem writes per row (N-tiles x wave columns of the tile it will use) */
+int aptp_conv_gemm_rowstat_slots(const AptpConvGemmParams* p);
 /* heuristic split-K the library would choose for this problem (host helper, no launch) */
 int aptp_conv_gemm_suggest_split_k(const AptpConvGemmParams* p);
 

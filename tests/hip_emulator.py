@@ -17,7 +17,8 @@ def _bf(x):
 
 
 def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colgate=None, gate_group=0, act=ACT_NONE,
-              corr=None, residual=None, depth=None, depth_in=None, out_f32=False, split_k=None, tile=0):
+              corr=None, residual=None, depth=None, depth_in=None, out_f32=False, split_k=None, tile=0,
+              rowstats=False, ln=None):
     B, H, W, C = x.shape
     assert C == pw.Cin and x.dtype == torch.bfloat16
     if pad is None:
@@ -28,7 +29,19 @@ def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colga
     xin = x.float().permute(0, 3, 1, 2)
     if ups:
         xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
-    y = F.conv2d(xin, w, pw.bias, stride=stride, padding=pad)
+    y = F.conv2d(xin, w, None, stride=stride, padding=pad)
+    if ln is not None:          # LayerNorm folded into the packed weights (include/aptp_hip.h, ln_stats)
+        stats, eps = ln
+        assert pw.ln_colsum is not None and pw.KH == 1
+        tot = stats.sum(0)
+        mean = tot[:, 0] / C
+        rstd = torch.rsqrt((tot[:, 1] / C - mean * mean).clamp_min(0) + eps)
+        mean, rstd = (t.reshape(B, 1, y.shape[2], y.shape[3]) for t in (mean, rstd))
+        y = rstd * (y - mean * pw.ln_colsum[None, :, None, None])
+    else:
+        assert pw.ln_colsum is None
+    if pw.bias is not None:
+        y = y + pw.bias[None, :, None, None]
     if rowbias is not None:
         y = y + rowbias[:, :pw.N, None, None]
     Ho, Wo = y.shape[2:]
@@ -58,10 +71,14 @@ def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colga
         y = (1 - d) * depth_in.float().permute(0, 3, 1, 2) + d * y
     y = y.permute(0, 2, 3, 1)
     y = y.contiguous() if out_f32 else _bf(y).contiguous()
+    stats = None
+    if rowstats:
+        yf = y.float().reshape(-1, y.shape[-1])
+        stats = torch.stack([yf.sum(1), (yf * yf).sum(1)], 1).reshape(1, -1, 2).contiguous()
     if out is not None:
         out.copy_(y)
-        return out
-    return y
+        y = out
+    return (y, stats) if rowstats else y
 
 
 def linear(x, pw, **kw):
@@ -70,6 +87,8 @@ def linear(x, pw, **kw):
         if kw.get(k) is not None:
             kw[k] = kw[k].unsqueeze(2)
     y = conv_gemm(x.unsqueeze(2), pw, pad=0, out=None if out is None else out.unsqueeze(2), **kw)
+    if "rowstats" in kw:
+        return (y[0].squeeze(2), y[1]) if kw["rowstats"] else (y.squeeze(2), None)
     return y.squeeze(2)
 
 

@@ -465,6 +465,65 @@ def test_layernorm(ops, cuda, rows, C):
     assert rel_l2(y.float().cpu(), ref) <= REL_L2_TOL
 
 
+@pytest.mark.parametrize("rows,C,N,tile", [(96, 64, 64, 0), (200, 192, 320, 0), (2048, 128, 320, 9), (300, 640, 640, 21),
+                                            (128, 320, 320, 34), (130, 640, 1280, 38), (256, 1280, 1280, 42)])
+def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile):
+    """the per-row (sum, sumsq) partials a producer GEMM emits (one slot per N-tile x wave column) add up to the
+    statistics of the bf16 values it stored, for 4- and 8-wave tiles, ragged rows and a residual in the epilogue"""
+    g = torch.Generator().manual_seed(rows + C + N)
+    x = _rand((1, rows, C), g).bfloat16()
+    w = _rand((N, C), g, 0.1).bfloat16()
+    b = _rand((N,), g, 0.5)
+    res = (_rand((1, rows, N), g) + 0.7).bfloat16()
+    pw = ops.pack_weight(w.float(), b, device=cuda)
+    y, st = ops.linear(x.to(cuda), pw, residual=res.to(cuda), rowstats=True, tile=tile, split_k=1)
+    ref = F.linear(x.float(), w.float(), b) + res.float()
+    assert rel_l2(y.float().cpu(), ref) <= REL_L2_TOL
+    assert st.shape[1] == rows and st.shape[2] == 2
+    tot = st.sum(0).cpu().double()
+    yf = y[0].double().cpu()
+    assert torch.allclose(tot[:, 0], yf.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(tot[:, 1], (yf * yf).sum(1), rtol=1e-5, atol=1e-3)
+    # a launch split along K emits no statistics: the caller falls back to the LayerNorm kernel
+    y2, st2 = ops.linear(x.to(cuda), pw, residual=res.to(cuda), rowstats=True, split_k=2)
+    assert st2 is None and rel_l2(y2.float().cpu(), ref) <= REL_L2_TOL
+
+
+@pytest.mark.parametrize("rows,C,N,tile,split_k,geglu", [(96, 64, 192, 0, 1, False), (200, 320, 384, 0, 1, False),
+                                                         (2048, 320, 128, 18, 1, False), (256, 1280, 640, 25, 3, False),
+                                                         (130, 640, 2560, 21, 1, True), (64, 1280, 5120, 40, 1, True),
+                                                         (300, 320, 1280, 9, 2, True)])
+def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, geglu):
+    """linear(LayerNorm(x)) in one launch (gamma folded into the weights, mean / rstd from the producer's row
+    statistics) against F.layer_norm + F.linear in fp32 on the same bf16 x: blocks.py:782-785,808-813,821-823,41-50"""
+    g = torch.Generator().manual_seed(rows * 7 + C + N)
+    gamma = 1.0 + 0.2 * _rand((C,), g)
+    beta = 0.3 * _rand((C,), g)
+    # the producer: an identity-free GEMM whose stored output IS the LayerNorm input (mean 0.4, spread 1.5, like test_layernorm)
+    src = _rand((1, rows, 64), g).bfloat16()
+    wp = _rand((C, 64), g, 0.19).bfloat16()
+    bp = torch.full((C,), 0.4)
+    x, st = ops.linear(src.to(cuda), ops.pack_weight(wp.float(), bp, device=cuda), rowstats=True, split_k=1)
+    w = _rand((N, C), g, 0.06).bfloat16()
+    b = _rand((N,), g, 0.2)
+    pw = ops.pack_weight(w.float(), b, geglu=geglu, device=cuda, ln_gamma=gamma, ln_beta=beta)
+    kw = {}
+    if geglu:
+        gate = (torch.rand((1, 32), generator=g) > 0.3).float()
+        kw = dict(colgate=gate.to(cuda).contiguous(), gate_group=N // 2 // 32)
+    y = ops.linear(x, pw, ln=(st, 1e-5), tile=tile, split_k=split_k, **kw)
+    n = F.layer_norm(x.float().cpu(), (C,), gamma, beta, 1e-5)
+    ref = F.linear(n, w.float(), b)
+    if geglu:
+        h, gg = ref.chunk(2, dim=-1)
+        m = gate.repeat_interleave(N // 2 // 32, dim=1)[:, None, :]
+        ref = (h * m) * F.gelu(gg * m)
+    assert y.shape == ref.shape
+    assert rel_l2(y.float().cpu(), ref) <= REL_L2_TOL
+    with pytest.raises(ValueError):
+        ops.linear(x, pw)                       # folded weights without statistics
+
+
 ATTN_CASES = [
     # B, heads, Lq, Lk
     (1, 1, 64, 64),

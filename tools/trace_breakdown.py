@@ -27,6 +27,17 @@ def main(path, skip_tail=0):
         if names[n - p:] == names[n - 2 * p:n - p] == names[n - 3 * p:n - 2 * p]:
             best = p
             break
+    # bench.py ends with other work (roofline leg, copies): if the tail is not the forward graph, locate the replays by a
+    # kernel that runs once per forward (the timestep sinusoid) and take the last three equal-length periods
+    marks = [i for i, nm in enumerate(names) if "sin_kernel" in nm]
+    if len(marks) >= 4 and (best is None or best < 100):
+        for j in range(len(marks) - 1, 2, -1):
+            p = marks[j] - marks[j - 1]
+            if p >= 100 and marks[j - 1] - marks[j - 2] == p and marks[j - 2] - marks[j - 3] == p \
+                    and names[marks[j - 1]:marks[j]] == names[marks[j - 2]:marks[j - 1]]:
+                best, n = p, marks[j]
+                rows = rows[:n]
+                break
     if best is None:
         print("no periodic tail found")
         return

@@ -42,6 +42,7 @@ class ConvGemmParams(Structure):
         ("rowstat_out", c_void_p), ("rowstat_slots", c_int32),
         ("ln_stats", c_void_p), ("ln_slots", c_int32),
         ("ln_colsum", c_void_p), ("ln_eps", c_float), ("ln_C", c_int32),
+        ("epilogue", c_int32),
     ]
 
 

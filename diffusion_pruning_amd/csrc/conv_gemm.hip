@@ -48,6 +48,7 @@ struct KParams {
   int M, HW, Nout;          // Nout = logical output columns (N/2 for GEGLU)
   int64_t ws_ld;            // workspace row stride (floats)
   int order;                // workgroup -> tile order (decode_block): 0 legacy, 1 weight-major, 2 activation-major
+  int epi16;                // 1: bf16 output (and residual / depth_in) rows are 16-byte aligned -> coalesced epilogue
   float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
   const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
 };
@@ -101,10 +102,11 @@ __device__ __forceinline__ void decode_block(const KParams& p, int tiles_m, int 
 // the row's mean / rstd finished from the producer's per-tile (sum, sumsq) partials
 struct RowCtx { int b, cls; float mean, rstd; };
 
+// first half of the epilogue of 4 consecutive packed columns: everything that needs only per-column / per-sample vectors
+// (folded LayerNorm, bias, time-embedding bias, width gate, activation, GroupNorm-beta correction) -> v[4]
 template <bool GEGLU>
-__device__ __forceinline__ void epilogue_quad(const KParams& p, int m, const RowCtx& rc, int n, float h[4], float g[4], float st[2]) {
+__device__ __forceinline__ void epilogue_pre(const KParams& p, const RowCtx& rc, int n, float h[4], float g[4], float v[4]) {
   const int b = rc.b, cls = rc.cls;
-  float v[4];
   if (p.ln_stats) {
     // y = LN(x) W^T with gamma folded into W:  rstd * (x W'^T - mean * colsum(W')) ; the beta term sits in `bias`
 #if APTP_ABLATE & 256
@@ -160,6 +162,14 @@ __device__ __forceinline__ void epilogue_quad(const KParams& p, int m, const Row
     const float4 cc = *reinterpret_cast<const float4*>(p.corr + ((int64_t)(b % p.corr_B) * 9 + cls) * p.Nout + c);
     v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w;
   }
+}
+
+template <bool GEGLU>
+__device__ __forceinline__ void epilogue_quad(const KParams& p, int m, const RowCtx& rc, int n, float h[4], float g[4], float st[2]) {
+  const int b = rc.b;
+  float v[4];
+  epilogue_pre<GEGLU>(p, rc, n, h, g, v);
+  const int c = GEGLU ? ((n >> 5) * 16 + (n & 15)) : n;   // logical output column of element 0
   if (p.residual && !(APTP_ABLATE & 64)) {
     const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldres + c);
     union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
@@ -334,6 +344,143 @@ __device__ __forceinline__ void tile_epilogue(const KParams& p, f32x4 (&acc)[MF]
         reinterpret_cast<float2*>(p.rstat_out)[(int64_t)(tn * WN + wn) * p.M + m] = o;   // [slots][M]: 16 rows = 128 B
       }
     }
+  }
+}
+
+// Coalesced epilogue (bf16 outputs whose rows are 16-byte aligned).  The MFMA accumulator layout gives a lane 4 columns
+// of 16 different rows, so storing from it costs one 8-byte access per (row, quad): 16 x 32-byte pieces per wave
+// instruction, and as many again for the residual / depth-gate operands.  The short-K launches of the masked U-Net
+// (1x1 projections with K = 128..1280) issue more vector-memory instructions in such an epilogue than in their whole
+// K-loop.  Here every wave transposes its 16 x WL fp32 row fragment through its own slice of the (now idle) staging LDS:
+// the per-column half of the epilogue runs in accumulator layout, then a lane owns 8 consecutive columns of one row, so
+// residual / depth_in are read and y is written with 16-byte accesses covering whole 128-byte lines, and the
+// residual loads are issued before the transpose so their latency overlaps it.  No workgroup barrier is needed after
+// the first one: a wave's LDS instructions execute in order.
+template <bool GEGLU, int MF, int NF, int WTM, int WTN, int WN>
+__device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)[MF][NF], int m0, int n0, int tn, int wm, int wn,
+                                                  int lane, const float (&ln_mean)[MF], const float (&ln_rstd)[MF], float* buf) {
+  constexpr int WL = GEGLU ? WTN / 2 : WTN;       // logical (stored) columns of this wave
+  constexpr int PITCH = WL + 4;                   // floats; +4 keeps the 16-byte LDS writes and reads conflict-free
+  constexpr int LPR = WL / 8;                     // lanes per row in the transposed layout
+  constexpr int RPP = 64 / LPR;                   // rows per pass
+  constexpr int NPASS = (16 + RPP - 1) / RPP;
+  constexpr bool POW2 = (LPR & (LPR - 1)) == 0;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int lrow = lane / LPR, lc8 = lane - lrow * LPR;
+  const int c0 = (GEGLU ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN)) + lc8 * 8;   // this lane's first logical column
+  const bool lane_on = lrow < RPP && c0 < p.Nout;
+  __bf16* const yb = reinterpret_cast<__bf16*>(p.y);
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int mbase = m0 + wm * WTM + i * 16;
+    // transposed domain: request the residual / depth-gate operands first
+    u32x4 rres[NPASS], rdin[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int r = ps * RPP + lrow, m2 = mbase + r;
+      const bool on = lane_on && r < 16 && m2 < p.M;
+      rres[ps] = (u32x4){0u, 0u, 0u, 0u}; rdin[ps] = (u32x4){0u, 0u, 0u, 0u};
+      if (on && p.residual && !(APTP_ABLATE & 64)) rres[ps] = *reinterpret_cast<const u32x4*>(p.residual + (int64_t)m2 * p.ldres + c0);
+      if (on && p.depth && !(APTP_ABLATE & 64)) rdin[ps] = *reinterpret_cast<const u32x4*>(p.depth_in + (int64_t)m2 * p.lddin + c0);
+    }
+    // accumulator domain: per-column half of the epilogue, fp32 row fragment -> LDS
+    {
+      const int m = mbase + frow;
+      RowCtx rc;
+      row_info(p, m < p.M ? m : p.M - 1, rc);
+      rc.mean = ln_mean[i]; rc.rstd = ln_rstd[i];
+      if constexpr (GEGLU) {
+        if constexpr (NF % 2 == 0) {
+#pragma unroll
+          for (int j = 0; j < NF; j += 2) {
+            const int n = n0 + wn * WTN + j * 16 + fq * 4;
+            float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) epilogue_pre<true>(p, rc, n, h, g, v);
+            *reinterpret_cast<float4*>(buf + frow * PITCH + (j / 2) * 16 + fq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int n = n0 + wn * WTN + j * 16 + fq * 4;
+          float h[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (n < p.N) epilogue_pre<false>(p, rc, n, h, h, v);
+          *reinterpret_cast<float4*>(buf + frow * PITCH + j * 16 + fq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    // transposed domain: + residual, depth lerp, round, 16-byte store, row statistics
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int r = ps * RPP + lrow, m2 = mbase + r;
+      const bool on = lane_on && r < 16 && m2 < p.M;
+      float v[8];
+      {
+        const int rr = r < 16 ? r : 15;
+        const float4 a = *reinterpret_cast<const float4*>(buf + rr * PITCH + lc8 * 8);
+        const float4 b4 = *reinterpret_cast<const float4*>(buf + rr * PITCH + lc8 * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+      }
+      if (p.residual && !(APTP_ABLATE & 64)) {
+        float f[8];
+        union { u32x4 v; uint4 s; } cv; cv.v = rres[ps];
+        unpack_bf16x8(cv.s, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += f[e];
+      }
+      if (p.depth && !(APTP_ABLATE & 64)) {
+        const float d = p.depth[((m2 < p.M ? m2 : p.M - 1) / p.HW) % p.depth_B];
+        float f[8];
+        union { u32x4 v; uint4 s; } cv; cv.v = rdin[ps];
+        unpack_bf16x8(cv.s, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (1.0f - d) * f[e] + d * v[e];
+      }
+      const uint4 o = pack_bf16x8(v);
+#if APTP_ABLATE & 32
+      asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+#else
+      if (on) *reinterpret_cast<uint4*>(yb + (int64_t)m2 * p.ldy + c0) = o;
+#endif
+      if constexpr (POW2) {
+        if (p.rstat_out) {       // statistics of the values as stored (bf16-rounded): what the consumer will read
+          float f[8], s0 = 0.f, s1 = 0.f;
+          unpack_bf16x8(o, f);
+          if (c0 < p.Nout) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s0 += f[e]; s1 += f[e] * f[e]; }
+          }
+#pragma unroll
+          for (int off = 1; off < LPR; off <<= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+          if (lrow < RPP && r < 16 && m2 < p.M && lc8 == 0) {   // (also for a wave past the last column: its slot reads 0)
+            float2 q; q.x = s0; q.y = s1;
+            reinterpret_cast<float2*>(p.rstat_out)[(int64_t)(tn * WN + wn) * p.M + m2] = q;
+          }
+        }
+      }
+    }
+  }
+}
+
+// picks the epilogue form (wave-uniform): the coalesced one needs 16-byte aligned bf16 rows (p.epi16, set on the host)
+template <int NW, int MF, int NF, int WTM, int WTN, int WN>
+__device__ __forceinline__ void run_epilogue(const KParams& p, f32x4 (&acc)[MF][NF], int m0, int n0, int tn, int wm, int wn, int lane,
+                                             int wave, const float (&ln_mean)[MF], const float (&ln_rstd)[MF], __bf16* smem) {
+  constexpr int PITCH_MAX = WTN + 4;
+  constexpr bool POW2 = ((WTN / 8) & (WTN / 8 - 1)) == 0;
+  if (p.epi16 && (POW2 || !p.rstat_out)) {
+    __syncthreads();                        // every wave is done reading the operand stages
+    float* buf = reinterpret_cast<float*>(smem) + wave * 16 * PITCH_MAX;
+    if (p.act == APTP_ACT_GEGLU) {
+      if constexpr (NF % 2 == 0) tile_epilogue_lds<true, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd, buf);
+    } else {
+      tile_epilogue_lds<false, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd, buf);
+    }
+  } else {
+    tile_epilogue<MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd);
   }
 }
 
@@ -515,7 +662,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
     }
     return;
   }
-  tile_epilogue<MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd);
+  run_epilogue<4, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, wave, ln_mean, ln_rstd, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -880,7 +1027,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     }
     return;
   }
-  tile_epilogue<MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd);
+  static_assert(NW * 16 * (WTN + 4) * 4 <= (int)sizeof(smem), "epilogue transpose buffer");
+  run_epilogue<NW, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, wave, ln_mean, ln_rstd, smem);
 }
 
 // split-K reducer + epilogue: one thread per (row, 4 packed columns)
@@ -1001,6 +1149,10 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   APTP_CHECK(!p->ln_stats || (p->ln_colsum && p->ln_slots > 0 && p->ln_C > 0 && p->KH == 1 && p->KW == 1 &&
                               ((uintptr_t)p->ln_stats % 8) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
              "conv_gemm: folded LayerNorm needs ln_colsum [N], ln_slots > 0, ln_C > 0 and a 1x1 filter");
+  k.epi16 = !p->out_f32 && p->ldy % 8 == 0 && ((uintptr_t)p->y % 16) == 0 && nout % 8 == 0 &&
+            (!p->residual || (p->ldres % 8 == 0 && ((uintptr_t)p->residual % 16) == 0)) &&
+            (!p->depth || (p->lddin % 8 == 0 && ((uintptr_t)p->depth_in % 16) == 0));
+  if (p->epilogue == 1) k.epi16 = 0;          // testing / tuning: force the accumulator-layout epilogue
   const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * 2;
   const int64_t wb = (int64_t)p->N * k.Ktot * 2;
   APTP_CHECK(xb < (1ll << 31) && wb < (1ll << 31), "conv_gemm: operand larger than 2 GiB");

@@ -174,6 +174,10 @@ TUNING = _load_tuning()
 # {"params": ConvGemmParams, "flops": algorithmic FLOPs, "keep": tensors referenced by the params}.
 LAUNCH_LOG = None
 
+# AptpConvGemmParams.epilogue for every launch: 0 = auto (coalesced epilogue where alignment allows), 1 = force the
+# accumulator-layout epilogue (A/B timing, tests of both forms)
+EPILOGUE = 0
+
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per device (stream-ordered reuse: kernels on one stream serialise)."""
@@ -249,6 +253,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.y, p.ldy, p.out_f32 = out.data_ptr(), _ld(out), int(out_f32)
     p.tile = tile
     p.order = order
+    p.epilogue = EPILOGUE
     p.split_k = 1
     if split_k is None and tile == 0:
         tuned = TUNING.get(tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU))

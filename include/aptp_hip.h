@@ -100,6 +100,8 @@ typedef struct {
   const float* ln_colsum;
   float ln_eps;
   int32_t ln_C;
+  int32_t epilogue;     /* 0 = auto (coalesced 16-byte stores through an LDS transpose when y / residual / depth_in rows are
+                         * 16-byte aligned), 1 = force the accumulator-layout epilogue (testing / tuning) */
 } AptpConvGemmParams;
 
 enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TILE_64x128 = 3, APTP_TILE_64x160 = 4,

@@ -35,6 +35,14 @@ def ops(cuda):
     return o
 
 
+@pytest.fixture(params=[0, 1], ids=["epi-auto", "epi-acc-layout"])
+def both_epilogues(ops, request):
+    """run a test with the coalesced (LDS-transposed) epilogue and with the accumulator-layout one"""
+    ops.EPILOGUE = request.param
+    yield request.param
+    ops.EPILOGUE = 0
+
+
 CONV_CASES = [
     # B, H, W, Cin, Cout, k, stride, ups, tile, split_k
     (2, 16, 16, 64, 64, 3, 1, 0, 0, 1),
@@ -274,7 +282,7 @@ def test_conv_workgroup_orders_agree(ops, cuda, case, order):
     assert torch.equal(auto, ref)
 
 
-def test_conv_strided_views(ops, cuda):
+def test_conv_strided_views(ops, cuda, both_epilogues):
     """input is a channel slice of a wider buffer, output written into a slice of a wider buffer"""
     g = torch.Generator().manual_seed(7)
     B, H, W, Cin, Cout = 2, 8, 8, 64, 96
@@ -292,7 +300,7 @@ def test_conv_strided_views(ops, cuda):
 
 
 @pytest.mark.parametrize("split_k", [1, 3])
-def test_conv_full_epilogue(ops, cuda, split_k):
+def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues):
     """bias + temb rowbias + per-sample width gate, then (separately) corr + residual + depth lerp"""
     g = torch.Generator().manual_seed(11)
     B, H, W, Cin, Cout, G = 4, 8, 8, 64, 64, 32
@@ -326,7 +334,7 @@ def test_conv_full_epilogue(ops, cuda, split_k):
 
 
 @pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6), (1, 21), (2, 22), (1, 9), (1, 15)])
-def test_linear_geglu(ops, cuda, split_k, tile):
+def test_linear_geglu(ops, cuda, split_k, tile, both_epilogues):
     g = torch.Generator().manual_seed(13)
     B, L, C, inner = 2, 96, 64, 256
     x = _rand((B, L, C), g).bfloat16()
@@ -343,7 +351,7 @@ def test_linear_geglu(ops, cuda, split_k, tile):
     assert rel_l2(y.float().cpu(), ref) <= REL_L2_TOL
 
 
-def test_linear_compact_geglu_and_silu_f32(ops, cuda):
+def test_linear_compact_geglu_and_silu_f32(ops, cuda, both_epilogues):
     g = torch.Generator().manual_seed(17)
     B, L, C, inner = 1, 50, 128, 512
     x = _rand((B, L, C), g).bfloat16()
@@ -467,7 +475,7 @@ def test_layernorm(ops, cuda, rows, C):
 
 @pytest.mark.parametrize("rows,C,N,tile", [(96, 64, 64, 0), (200, 192, 320, 0), (2048, 128, 320, 9), (300, 640, 640, 21),
                                             (128, 320, 320, 34), (130, 640, 1280, 38), (256, 1280, 1280, 42)])
-def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile):
+def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile, both_epilogues):
     """the per-row (sum, sumsq) partials a producer GEMM emits (one slot per N-tile x wave column) add up to the
     statistics of the bf16 values it stored, for 4- and 8-wave tiles, ragged rows and a residual in the epilogue"""
     g = torch.Generator().manual_seed(rows + C + N)
@@ -493,7 +501,7 @@ def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile):
                                                          (2048, 320, 128, 18, 1, False), (256, 1280, 640, 25, 3, False),
                                                          (130, 640, 2560, 21, 1, True), (64, 1280, 5120, 40, 1, True),
                                                          (300, 320, 1280, 9, 2, True)])
-def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, geglu):
+def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, geglu, both_epilogues):
     """linear(LayerNorm(x)) in one launch (gamma folded into the weights, mean / rstd from the producer's row
     statistics) against F.layer_norm + F.linear in fp32 on the same bf16 x: blocks.py:782-785,808-813,821-823,41-50"""
     g = torch.Generator().manual_seed(rows * 7 + C + N)

@@ -42,7 +42,7 @@ class ConvGemmParams(Structure):
         ("rowstat_out", c_void_p), ("rowstat_slots", c_int32),
         ("ln_stats", c_void_p), ("ln_slots", c_int32),
         ("ln_colsum", c_void_p), ("ln_eps", c_float), ("ln_C", c_int32),
-        ("epilogue", c_int32),
+        ("tile_counters", c_void_p), ("epilogue", c_int32),
     ]
 
 
@@ -54,6 +54,7 @@ class GroupNormParams(Structure):
         ("gamma", c_void_p), ("beta", c_void_p),
         ("eps", c_float), ("silu", c_int32),
         ("workspace", c_void_p), ("variant", c_int32),
+        ("counters", c_void_p),
     ]
 
 
@@ -153,6 +154,7 @@ EXPORTS = [
     ("aptp_conv_gemm_workspace_bytes", c_int64, [POINTER(ConvGemmParams)]),
     ("aptp_conv_gemm_suggest_split_k", c_int, [POINTER(ConvGemmParams)]),
     ("aptp_conv_gemm_rowstat_slots", c_int, [POINTER(ConvGemmParams)]),
+    ("aptp_conv_gemm_tiles", c_int, [POINTER(ConvGemmParams)]),
     ("aptp_groupnorm", c_int, [POINTER(GroupNormParams), c_void_p]),
     ("aptp_groupnorm_nchunk", c_int, [c_int]),
     ("aptp_groupnorm_workspace_bytes", c_int64, [POINTER(GroupNormParams)]),

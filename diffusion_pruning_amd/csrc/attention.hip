@@ -168,13 +168,15 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.c;
     const float m_new = fmaxf(m_run, mx);       // finite: every tile holds >= 1 valid key
-    const float alpha = exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
+    // (raw v_exp_f32: arguments are <= 0, so the range scaling / denormal fix-up exp2f() wraps around the instruction --
+    // compare, two selects, an add and an ldexp per score -- buys nothing; results below 2^-126 flush to zero)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
     float rs = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(__builtin_fmaf(sacc[t][r], p.c, -m_new));   // masked keys: -inf * c - m = -inf -> 0
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][r], p.c, -m_new));   // masked keys: -inf * c - m = -inf -> 0
         sacc[t][r] = pv;
         rs += pv;
       }

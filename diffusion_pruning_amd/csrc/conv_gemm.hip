@@ -48,6 +48,7 @@ struct KParams {
   int M, HW, Nout;          // Nout = logical output columns (N/2 for GEGLU)
   int64_t ws_ld;            // workspace row stride (floats)
   int order;                // workgroup -> tile order (decode_block): 0 legacy, 1 weight-major, 2 activation-major
+  int* counters;            // in-kernel split-K: one arrival counter per output tile (zero on entry, left zero)
   int epi16;                // 1: bf16 output (and residual / depth_in) rows are 16-byte aligned -> coalesced epilogue
   float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
   const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
@@ -238,8 +239,9 @@ template <int MF>
 struct LnRaw { float2 v[4][MF]; int mr[MF]; };
 
 template <int MF, int WTM>
-__device__ __forceinline__ void ln_rows_issue(const KParams& p, int m0, int wm, int lane, LnRaw<MF>& raw) {
-  if (!p.ln_stats || p.split_k > 1 || (APTP_ABLATE & 128)) return;      // (split-K: the reducer finishes the rows itself)
+__device__ __forceinline__ void ln_rows_issue(const KParams& p, int m0, int wm, int lane, LnRaw<MF>& raw, bool split_ok = false) {
+  // (split-K: only the workgroup that combines the slices needs the rows, and asks for them then)
+  if (!p.ln_stats || (p.split_k > 1 && !split_ok) || (APTP_ABLATE & 128)) return;
   const int frow = lane & 15, fq = lane >> 4;
   const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
 #pragma unroll
@@ -265,8 +267,9 @@ __device__ __forceinline__ void ln_rows_issue(const KParams& p, int m0, int wm, 
 }
 
 template <int MF>
-__device__ __forceinline__ void ln_rows_finish(const KParams& p, int lane, const LnRaw<MF>& raw, float (&ln_mean)[MF], float (&ln_rstd)[MF]) {
-  if (!p.ln_stats || p.split_k > 1 || (APTP_ABLATE & 128)) return;
+__device__ __forceinline__ void ln_rows_finish(const KParams& p, int lane, const LnRaw<MF>& raw, float (&ln_mean)[MF], float (&ln_rstd)[MF],
+                                               bool split_ok = false) {
+  if (!p.ln_stats || (p.split_k > 1 && !split_ok) || (APTP_ABLATE & 128)) return;
   const int fq = lane >> 4;
   const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
   float lna[MF], lna2[MF];
@@ -465,6 +468,64 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
   }
 }
 
+// In-kernel split-K reduction (p.counters != nullptr).  Every K-slice workgroup of an output tile stores its fp32
+// accumulators to its slab in ACCUMULATOR order (float4 (i,j) of thread t at [(i*NF+j)*NT + t]: 1 KiB per wave
+// instruction, written and read by the same thread index, no transposition), publishes it (write-through stores, drained)
+// and draws a ticket from the tile's arrival counter; the workgroup that draws split_k-1 acquires, re-reads ALL slabs in
+// slice order (its own included, so the sum does not depend on which slice arrived last: deterministic), resets the
+// counter for the next launch and goes on to the ordinary epilogue.  Placement-independent: any distribution of a
+// tile's slices over CUs / XCDs is correct (cdna_hip_programming.md, projection GEMM item 2).  Replaces the
+// splitk_reduce_kernel launch (5.9-6.6 us + a kernel boundary each, 56-62 per forward).
+template <int NT, int MF, int NF>
+__device__ __forceinline__ bool splitk_combine(const KParams& p, f32x4 (&acc)[MF][NF], int tile, int kz, int tid, int* lds_word) {
+  constexpr int PER = MF * NF;
+  float4* const slab = reinterpret_cast<float4*>(p.ws) + (int64_t)tile * p.split_k * (PER * NT);
+  float4* const mine = slab + (int64_t)kz * (PER * NT);
+  // The slab is stored WRITE-THROUGH (sc1: 16-byte buffer stores with aux = 16), which publishes it without an
+  // agent-scope release fence: a release writes back the whole XCD L2's dirty lines and costs every slice workgroup
+  // 2-6 us on its tail (measured: the fence form ran 1-4 us per launch behind the two-launch form even at split_k = 2).
+  {
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, PER * NT * 16, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), srsrc, ((i * NF + j) * NT + tid) * 16, 0, 16);
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+  __syncthreads();
+  if (tid == 0) *lds_word = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int ticket = *reinterpret_cast<volatile int*>(lds_word);
+  if (ticket != p.split_k - 1) return false;
+  if (tid == 0) {
+    __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.split_k; ++z) {
+    const float4* src = slab + (int64_t)z * (PER * NT);
+    float4 t[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) t[i][j] = src[(i * NF + j) * NT + tid];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        acc[i][j][0] += t[i][j].x; acc[i][j][1] += t[i][j].y; acc[i][j][2] += t[i][j].z; acc[i][j][3] += t[i][j].w;
+      }
+  }
+  return true;
+}
+
 // picks the epilogue form (wave-uniform): the coalesced one needs 16-byte aligned bf16 rows (p.epi16, set on the host)
 template <int NW, int MF, int NF, int WTM, int WTN, int WN>
 __device__ __forceinline__ void run_epilogue(const KParams& p, f32x4 (&acc)[MF][NF], int m0, int n0, int tn, int wm, int wn, int lane,
@@ -646,6 +707,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
 
   // ---- epilogue --------------------------------------------------------------------------------------------------
   // acc[i][j][r] = out[m = m0 + wm*WTM + i*16 + (lane&15)][n = n0 + wn*WTN + j*16 + (lane>>4)*4 + r]
+  if (p.split_k > 1 && p.counters) {
+    if (!splitk_combine<256, MF, NF>(p, acc, tm * tiles_n + tn, kz, tid, reinterpret_cast<int*>(smem))) return;
+    ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw, true);
+    ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd, true);
+  } else
   if (p.split_k > 1) {
     float* ws = p.ws + (int64_t)kz * p.M * p.ws_ld;
 #pragma unroll
@@ -1011,6 +1077,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     g_stamps[slot * 4 + 3] = __builtin_readcyclecounter() - st_begin;
   }
 #endif
+  if (p.split_k > 1 && p.counters) {
+    if (!splitk_combine<NT, MF, NF>(p, acc, tm * tiles_n + tn, kz, tid, reinterpret_cast<int*>(smem))) return;
+    ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw, true);
+    ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd, true);
+  } else
   if (p.split_k > 1) {
     float* ws = p.ws + (int64_t)kz * p.M * p.ws_ld;
 #pragma unroll
@@ -1042,13 +1113,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
   if (p.act == APTP_ACT_GEGLU) n = (q >> 2) * 32 + (q & 3) * 4;
   else n = q * 4;
   float h[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < p.split_k; ++z) {
-    const float* row = p.ws + ((int64_t)z * p.M + m) * p.ws_ld;
-    const float4 a = *reinterpret_cast<const float4*>(row + n);
-    h[0] += a.x; h[1] += a.y; h[2] += a.z; h[3] += a.w;
-    if (p.act == APTP_ACT_GEGLU) {
-      const float4 c = *reinterpret_cast<const float4*>(row + n + 16);
-      g[0] += c.x; g[1] += c.y; g[2] += c.z; g[3] += c.w;
+  // four slabs in flight per thread (one slab per round trip otherwise); the adds stay in slice order => deterministic
+  for (int z0 = 0; z0 < p.split_k; z0 += 4) {
+    float4 a[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int z = z0 + u < p.split_k ? z0 + u : z0;
+      const float* row = p.ws + ((int64_t)z * p.M + m) * p.ws_ld;
+      a[u] = *reinterpret_cast<const float4*>(row + n);
+      if (p.act == APTP_ACT_GEGLU) c[u] = *reinterpret_cast<const float4*>(row + n + 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (z0 + u < p.split_k) {
+        h[0] += a[u].x; h[1] += a[u].y; h[2] += a[u].z; h[3] += a[u].w;
+        if (p.act == APTP_ACT_GEGLU) { g[0] += c[u].x; g[1] += c[u].y; g[2] += c[u].z; g[3] += c[u].w; }
+      }
     }
   }
   RowCtx rc;
@@ -1149,6 +1229,7 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   APTP_CHECK(!p->ln_stats || (p->ln_colsum && p->ln_slots > 0 && p->ln_C > 0 && p->KH == 1 && p->KW == 1 &&
                               ((uintptr_t)p->ln_stats % 8) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
              "conv_gemm: folded LayerNorm needs ln_colsum [N], ln_slots > 0, ln_C > 0 and a 1x1 filter");
+  k.counters = p->tile_counters;
   k.epi16 = !p->out_f32 && p->ldy % 8 == 0 && ((uintptr_t)p->y % 16) == 0 && nout % 8 == 0 &&
             (!p->residual || (p->ldres % 8 == 0 && ((uintptr_t)p->residual % 16) == 0)) &&
             (!p->depth || (p->lddin % 8 == 0 && ((uintptr_t)p->depth_in % 16) == 0));
@@ -1200,7 +1281,24 @@ extern "C" int aptp_debug_read_stamps(unsigned long long* dst, int n_words) {
 
 extern "C" int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p) {
   if (!p || p->split_k <= 1) return 0;
-  return (int64_t)p->split_k * p->B * p->Hout * p->Wout * p->N * (int64_t)sizeof(float);
+  // covers both slab forms: [split_k][M][N] rows (separate reduce launch) and whole padded tiles in accumulator order
+  // (in-kernel reduction)
+  const int64_t M = (int64_t)p->B * p->Hout * p->Wout;
+  const int t = pick_tile(p, (int)M);
+  int64_t mp = M, np = p->N;
+  if (t > 0 && t < kNumTiles) {
+    mp = (M + kTiles[t].bm - 1) / kTiles[t].bm * kTiles[t].bm;
+    np = ((int64_t)p->N + kTiles[t].bn - 1) / kTiles[t].bn * kTiles[t].bn;
+  }
+  return (int64_t)p->split_k * mp * np * (int64_t)sizeof(float);
+}
+
+extern "C" int aptp_conv_gemm_tiles(const AptpConvGemmParams* p) {
+  if (!p) return 0;
+  const int64_t M = (int64_t)p->B * p->Hout * p->Wout;
+  const int t = pick_tile(p, (int)M);
+  if (t <= 0 || t >= kNumTiles) return 0;
+  return (int)(((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((p->N + kTiles[t].bn - 1) / kTiles[t].bn));
 }
 
 extern "C" int aptp_conv_gemm_rowstat_slots(const AptpConvGemmParams* p) {
@@ -1229,6 +1327,7 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   const int rc = fill_kparams(p, k);
   if (rc != APTP_OK) return rc;
   if (k.split_k > 1) APTP_CHECK(k.ws != nullptr && ((uintptr_t)k.ws % 16) == 0, "conv_gemm: split_k > 1 needs a 16B-aligned workspace");
+  if (k.split_k == 1) k.counters = nullptr;
   hipStream_t s = (hipStream_t)stream;
   int t = pick_tile(p, k.M);
   if (t < 0 || t >= kNumTiles) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
@@ -1239,8 +1338,8 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   }
   if (k.rstat_out) {
     const int slots = ((k.N + kTiles[t].bn - 1) / kTiles[t].bn) * kTiles[t].wn;
-    if (k.split_k != 1 || k.rstat_slots != slots) {
-      aptp_set_error("conv_gemm: rowstat_out needs split_k == 1 and rowstat_slots == aptp_conv_gemm_rowstat_slots() (%d), got split_k %d, slots %d",
+    if ((k.split_k != 1 && !k.counters) || k.rstat_slots != slots) {
+      aptp_set_error("conv_gemm: rowstat_out needs split_k == 1 (or the in-kernel reduction) and rowstat_slots == aptp_conv_gemm_rowstat_slots() (%d), got split_k %d, slots %d",
                      slots, k.split_k, k.rstat_slots);
       return APTP_EINVAL;
     }
@@ -1295,7 +1394,7 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
   }
   APTP_LAUNCH_CHECK();
-  if (k.split_k > 1) {
+  if (k.split_k > 1 && !k.counters) {
     const int quads = (k.act == APTP_ACT_GEGLU) ? k.N / 8 : k.N / 4;
     const int64_t total = (int64_t)k.M * quads;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);

@@ -19,18 +19,31 @@ struct GnK {
   const float* gamma; const float* beta; float eps; int silu;
   float* ws; int nchunk;
   float* fin;                // finalised [B, G, 2] (mean, rstd), written by gn_finalize_kernel
+  int* counters;             // optional [B] arrival counters (zero on entry, left zero): the last stage-1 workgroup of a
+                             // sample folds the partials itself and gn_finalize_kernel is not launched
   int TPR, RPAR;             // threads per row (= min(CO,256)), rows processed in parallel (256/TPR)
 };
 
 // stage 1.5: one workgroup per sample folds the nchunk partials ONCE (fixed order => deterministic).  Without it every
 // apply workgroup re-read all partials (32 KB each): more bytes than the activation tile it normalises.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnK p) {
-  const int tid = threadIdx.x, b = blockIdx.x;
+__device__ __forceinline__ void gn_finalize_sample(const GnK& p, int b, int tid) {
   const int g = tid >> 3, sub = tid & 7;
   float a = 0.f, a2 = 0.f;
   if (g < p.G) {
-    const float* w = p.ws + ((int64_t)b * p.nchunk * p.G + g) * 2;
-    for (int c = sub; c < p.nchunk; c += 8) { a += w[(int64_t)c * p.G * 2]; a2 += w[(int64_t)c * p.G * 2 + 1]; }
+    // 8 partials in flight per thread (the chunk loop is a chain of L2 round trips otherwise: 16 of them at HW = 4096);
+    // the adds keep the order c = sub, sub + 8, ... => deterministic
+    const float2* w = reinterpret_cast<const float2*>(p.ws) + (int64_t)b * p.nchunk * p.G + g;
+    for (int c0 = sub; c0 < p.nchunk; c0 += 64) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 8 * u;
+        v[u] = w[(int64_t)(c < p.nchunk ? c : sub) * p.G];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c0 + 8 * u < p.nchunk) { a += v[u].x; a2 += v[u].y; }
+    }
   }
 #pragma unroll
   for (int off = 4; off >= 1; off >>= 1) {
@@ -46,6 +59,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnK p) {
     p.fin[((int64_t)b * p.G + g) * 2 + 1] = rsqrtf(var + p.eps);
   }
 }
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnK p) { gn_finalize_sample(p, blockIdx.x, threadIdx.x); }
 
 template <int NP>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
@@ -120,9 +135,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
   }
   if (g < p.G && sub == 0) {
     float* o = p.ws + (((int64_t)b * p.nchunk + chunk) * p.G + g) * 2;
-    o[0] = a;
-    o[1] = a2;
+    if (p.counters) {
+      // fused finalize: the partial is one naturally aligned 8-byte agent-scope (write-through) store
+      union { float f[2]; unsigned long long u; } pk; pk.f[0] = a; pk.f[1] = a2;
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(o), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      o[0] = a;
+      o[1] = a2;
+    }
   }
+  if (!p.counters) return;
+  // Last-arriver finalize (replaces the gn_finalize_kernel launch, 5.5 us + a kernel boundary per GroupNorm): every
+  // workgroup drains its write-through partials and takes a ticket on the sample's counter; the one that draws
+  // nchunk-1 acquires, folds all partials in the fixed order of gn_finalize_sample (deterministic) and resets the counter.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(&red[0][0]);
+  if (tid == 0) *flag = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*reinterpret_cast<volatile int*>(flag) != p.nchunk - 1) return;
+  if (tid == 0) {
+    __hip_atomic_store(p.counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  gn_finalize_sample(p, b, tid);
 }
 
 template <int NP>
@@ -471,6 +509,7 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   k.gamma = p->gamma; k.beta = p->beta; k.eps = p->eps; k.silu = p->silu;
   k.ws = (float*)p->workspace; k.nchunk = aptp_groupnorm_nchunk(p->HW);
   k.fin = k.ws + (int64_t)p->B * k.nchunk * p->groups * 2;
+  k.counters = p->counters;
   k.TPR = CO < 256 ? CO : 256;
   k.RPAR = 256 / k.TPR;
   hipStream_t s = (hipStream_t)stream;
@@ -513,11 +552,11 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   dim3 grid2(nchunk2, p->B);
   if (CO <= 256) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
+    if (!k.counters) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(256), 0, s, k);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<2>, grid1, dim3(256), 0, s, k);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
+    if (!k.counters) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(256), 0, s, k);
   }
   APTP_LAUNCH_CHECK();

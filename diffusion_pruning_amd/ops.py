@@ -159,7 +159,8 @@ def tuning_key(M, N, Cin, taps, stride, ups, geglu) -> str:
 def _load_tuning():
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+    # (APTP_TUNING=<file> substitutes another table: A/B timing of tuning runs)
+    path = os.environ.get("APTP_TUNING") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
@@ -173,6 +174,32 @@ TUNING = _load_tuning()
 # Optional launch recorder used by bench.py's roofline leg: when a list, every aptp_conv_gemm launch appends
 # {"params": ConvGemmParams, "flops": algorithmic FLOPs, "keep": tensors referenced by the params}.
 LAUNCH_LOG = None
+
+# Split-K launches combine their K-slices inside the kernel (AptpConvGemmParams.tile_counters) instead of launching
+# splitk_reduce_kernel; False restores the two-launch form (A/B timing, tests of both forms)
+SPLITK_IN_KERNEL = True
+_counters = {}
+_N_COUNTERS = 1 << 16
+
+
+def _tile_counters(device):
+    """zero-initialised arrival counters shared by every split-K launch on the device (each launch leaves them zero).
+    Never created while a stream is capturing (the fill would only run at replay): such a call gets None and uses the
+    separate reduce launch."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _counters.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        buf = torch.zeros(_N_COUNTERS, dtype=torch.int32, device=device)
+        _counters[key] = buf
+    return buf
+
+
+# GroupNorm on the large maps: True lets the last statistics workgroup of a sample finalise mean / rstd (two launches
+# instead of three).  Measured SLOWER on MI355X (162.5 vs 164.7 steps/s: 128 tickets on one counter + the acquire cost
+# more than the 5.5 us launch they replace), so it is off; kept for tests and as a measured negative result.
+GN_FUSED_FINALIZE = False
 
 # AptpConvGemmParams.epilogue for every launch: 0 = auto (coalesced epilogue where alignment allows), 1 = force the
 # accumulator-layout epilogue (A/B timing, tests of both forms)
@@ -255,17 +282,30 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.order = order
     p.epilogue = EPILOGUE
     p.split_k = 1
+    in_kernel = None                 # split-K form: tuned per shape; untuned shapes combine in-kernel up to 4 slices
+    explicit_split = split_k is not None
     if split_k is None and tile == 0:
         tuned = TUNING.get(tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU))
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
+            in_kernel = bool(tuned.get("in_kernel", 0))
             if order == 0:
                 p.order = tuned.get("order", 1)     # tables tuned before the XCD-aware orders existed mean the legacy order
     if split_k is None:
         split_k = lib.aptp_conv_gemm_suggest_split_k(ctypes.byref(p))
     p.split_k = max(1, int(split_k))
+    ws = cnt = None
+    if p.split_k > 1:
+        if in_kernel is None:
+            in_kernel = p.split_k <= 4 or explicit_split
+        if SPLITK_IN_KERNEL and in_kernel and lib.aptp_conv_gemm_tiles(ctypes.byref(p)) <= _N_COUNTERS:
+            cnt = _tile_counters(x.device)
+            if cnt is not None:
+                p.tile_counters = cnt.data_ptr()
+        ws = _workspace(lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(p)), x.device)
+        p.workspace = ws.data_ptr()
     stats = None
-    if rowstats and p.split_k == 1:
+    if rowstats and (p.split_k == 1 or cnt is not None):
         slots = lib.aptp_conv_gemm_rowstat_slots(ctypes.byref(p))
         stats = torch.empty(slots, B * Hout * Wout, 2, dtype=torch.float32, device=x.device)
         p.rowstat_out, p.rowstat_slots = stats.data_ptr(), slots
@@ -279,14 +319,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         p.ln_eps, p.ln_C = ln_eps, Cx
     elif pw.ln_colsum is not None:
         raise ValueError("conv_gemm: weights with a folded LayerNorm need ln=(stats, eps)")
-    ws = None
-    if p.split_k > 1:
-        ws = _workspace(lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(p)), x.device)
-        p.workspace = ws.data_ptr()
     _lib.check(lib.aptp_conv_gemm(ctypes.byref(p), _stream()), "aptp_conv_gemm")
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * pw.KH * pw.KW * pw.Cin,
-                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln)})
+                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt)})
     return (out, stats) if rowstats else out
 
 
@@ -333,6 +369,9 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
         ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
     p.variant = variant
     p.workspace = ws.data_ptr()
+    cnt = _tile_counters(x.device) if (GN_FUSED_FINALIZE and B <= _N_COUNTERS) else None
+    if cnt is not None:
+        p.counters = cnt.data_ptr()
     _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
     return (out, ws) if keep_stats else out
 

@@ -100,6 +100,10 @@ typedef struct {
   const float* ln_colsum;
   float ln_eps;
   int32_t ln_C;
+  int32_t* tile_counters; /* optional, split_k > 1: >= aptp_conv_gemm_tiles() int32 words, ZERO on entry and left zero: the
+                           * K-slices are then combined inside the launch by the last-arriving workgroup of each output tile
+                           * (one agent-scope release / acquire per tile, slabs re-read in slice order: deterministic) and no
+                           * reduce kernel is launched; words may be shared by launches of one stream */
   int32_t epilogue;     /* 0 = auto (coalesced 16-byte stores through an LDS transpose when y / residual / depth_in rows are
                          * 16-byte aligned), 1 = force the accumulator-layout epilogue (testing / tuning) */
 } AptpConvGemmParams;
@@ -127,6 +131,8 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);
+/* output tiles of the launch (size of tile_counters) */
+int aptp_conv_gemm_tiles(const AptpConvGemmParams* p);
 /* number of row-statistics slots a launch of this problem writes per row (N-tiles x wave columns of the tile it will use) */
 int aptp_conv_gemm_rowstat_slots(const AptpConvGemmParams* p);
 /* heuristic split-K the library would choose for this problem (host helper, no launch) */
@@ -154,6 +160,10 @@ typedef struct {
   /* 0 = auto; 1 = three launches (stats, finalise, apply): the only form that fills the workspace partials
    * aptp_groupnorm_bwd consumes; 2 = one launch, each workgroup owning whole groups of one sample (small maps). */
   int32_t variant;
+  /* optional, three-launch form only: >= B int32 words, ZERO on entry and left zero.  The last statistics workgroup of
+   * each sample then folds the partials itself (write-through partial stores, one agent-scope acquire) and the
+   * finalise launch is skipped: two launches instead of three. */
+  int32_t* counters;
 } AptpGroupNormParams;
 
 int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream);

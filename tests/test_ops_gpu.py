@@ -35,6 +35,22 @@ def ops(cuda):
     return o
 
 
+@pytest.fixture(params=[True, False], ids=["splitk-in-kernel", "splitk-reduce-launch"])
+def both_splitk(ops, request):
+    """run a test with the in-kernel split-K reduction and with the separate reduce launch"""
+    ops.SPLITK_IN_KERNEL = request.param
+    yield request.param
+    ops.SPLITK_IN_KERNEL = True
+
+
+@pytest.fixture(params=[True, False], ids=["gn-fused-finalize", "gn-finalize-launch"])
+def both_gn_forms(ops, request):
+    """GroupNorm with the last-arriver finalise inside the statistics kernel and with the separate finalise launch"""
+    ops.GN_FUSED_FINALIZE = request.param
+    yield request.param
+    ops.GN_FUSED_FINALIZE = False
+
+
 @pytest.fixture(params=[0, 1], ids=["epi-auto", "epi-acc-layout"])
 def both_epilogues(ops, request):
     """run a test with the coalesced (LDS-transposed) epilogue and with the accumulator-layout one"""
@@ -238,7 +254,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_plain(ops, cuda, case):
+def test_conv_plain(ops, cuda, case, both_splitk):
     B, H, W, Cin, Cout, k, stride, ups, tile, split_k = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = _rand((B, Cin, H, W), g).bfloat16()
@@ -254,6 +270,38 @@ def test_conv_plain(ops, cuda, case):
     assert got.shape == ref.shape
     e = rel_l2(got, ref)
     assert e <= REL_L2_TOL, f"rel-L2 {e:.3e}"
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,tile,split_k", [(4, 16, 2560, 1280, 1, 30, 3), (4, 16, 640, 1280, 3, 34, 4),
+                                                         (4, 8, 1280, 640, 3, 40, 12), (4, 32, 320, 640, 3, 34, 2),
+                                                         (4, 32, 1920, 320, 3, 19, 8), (1, 24, 64, 200, 3, 12, 3)])
+def test_splitk_in_kernel_matches_reduce_launch_bitwise_and_is_stable(ops, cuda, B, H, Cin, Cout, k, tile, split_k):
+    """The in-kernel reduction re-reads every slab in slice order, so it must equal the reduce-launch form BIT FOR BIT
+    whichever workgroup arrives last, on every one of many back-to-back launches (stale slab lines in a CU's L1 / another
+    XCD's L2, a lost counter reset or a torn ticket would show up as a differing or missing tile), with other split-K
+    launches of different tile counts interleaved on the same counters."""
+    g = torch.Generator().manual_seed(B * H + Cin + Cout)
+    x = nhwc(_rand((B, Cin, H, H), g)).bfloat16().to(cuda)
+    res = nhwc(_rand((B, Cout, H, H), g)).bfloat16().to(cuda)
+    pw = ops.pack_weight(_rand((Cout, Cin, k, k), g, 1.0 / math.sqrt(Cin * k * k)), _rand((Cout,), g, 0.1), device=cuda)
+    x2 = nhwc(_rand((2, 256, 8, 8), g)).bfloat16().to(cuda)
+    pw2 = ops.pack_weight(_rand((136, 256, 3, 3), g, 0.02), None, device=cuda)
+    ops.SPLITK_IN_KERNEL = False
+    try:
+        ref = ops.conv_gemm(x, pw, residual=res, tile=tile, split_k=split_k).clone()
+        ref2 = ops.conv_gemm(x2, pw2, tile=18, split_k=5).clone()
+    finally:
+        ops.SPLITK_IN_KERNEL = True
+    out = torch.empty_like(ref)
+    bad = 0
+    for it in range(60):
+        ops.conv_gemm(x, pw, residual=res, tile=tile, split_k=split_k, out=out)
+        y2 = ops.conv_gemm(x2, pw2, tile=18, split_k=5)
+        if it % 6 == 5:
+            bad += int(not torch.equal(out, ref)) + int(not torch.equal(y2, ref2))
+    torch.cuda.synchronize()
+    assert bad == 0
+    assert int(ops._tile_counters(cuda).abs().sum()) == 0          # every launch left its counters at zero
 
 
 ORDER_CASES = [
@@ -300,7 +348,7 @@ def test_conv_strided_views(ops, cuda, both_epilogues):
 
 
 @pytest.mark.parametrize("split_k", [1, 3])
-def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues):
+def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues, both_splitk):
     """bias + temb rowbias + per-sample width gate, then (separately) corr + residual + depth lerp"""
     g = torch.Generator().manual_seed(11)
     B, H, W, Cin, Cout, G = 4, 8, 8, 64, 64, 32
@@ -334,7 +382,7 @@ def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues):
 
 
 @pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6), (1, 21), (2, 22), (1, 9), (1, 15)])
-def test_linear_geglu(ops, cuda, split_k, tile, both_epilogues):
+def test_linear_geglu(ops, cuda, split_k, tile, both_epilogues, both_splitk):
     g = torch.Generator().manual_seed(13)
     B, L, C, inner = 2, 96, 64, 256
     x = _rand((B, L, C), g).bfloat16()
@@ -395,7 +443,7 @@ GN_CASES = [
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", GN_CASES)
-def test_groupnorm(ops, cuda, case, variant):
+def test_groupnorm(ops, cuda, case, variant, both_gn_forms):
     """variant 1 = three launches (the form the backward consumes), 2 = one launch with group-owning workgroups,
     0 = the library's choice; all against F.group_norm in fp32"""
     B, H, W, C, G, silu, eps = case
@@ -422,7 +470,7 @@ def test_groupnorm(ops, cuda, case, variant):
 
 
 @pytest.mark.parametrize("variant", [1, 2])
-def test_groupnorm_strided_view_and_determinism(ops, cuda, variant):
+def test_groupnorm_strided_view_and_determinism(ops, cuda, variant, both_gn_forms):
     """input = channel slice of a wider (concat) buffer, output into a slice too; two runs are bit-identical"""
     B, H, W, C, G = 2, 16, 16, 640, 32
     g = torch.Generator().manual_seed(11)
@@ -492,16 +540,26 @@ def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile, both_epilogues
     yf = y[0].double().cpu()
     assert torch.allclose(tot[:, 0], yf.sum(1), rtol=1e-5, atol=1e-3)
     assert torch.allclose(tot[:, 1], (yf * yf).sum(1), rtol=1e-5, atol=1e-3)
-    # a launch split along K emits no statistics: the caller falls back to the LayerNorm kernel
-    y2, st2 = ops.linear(x.to(cuda), pw, residual=res.to(cuda), rowstats=True, split_k=2)
-    assert st2 is None and rel_l2(y2.float().cpu(), ref) <= REL_L2_TOL
+    # split along K: the workgroup that combines the slices emits the statistics (in-kernel reduction) ...
+    y2, st2 = ops.linear(x.to(cuda), pw, residual=res.to(cuda), rowstats=True, tile=tile, split_k=2)
+    assert rel_l2(y2.float().cpu(), ref) <= REL_L2_TOL
+    if C >= 128:      # (a single K-step cannot be split)
+        y2f = y2[0].double().cpu()
+        assert torch.allclose(st2.sum(0).cpu().double()[:, 0], y2f.sum(1), rtol=1e-5, atol=1e-3)
+    # ... and with the separate reduce launch there are none: the caller falls back to the LayerNorm kernel
+    ops.SPLITK_IN_KERNEL = False
+    try:
+        y3, st3 = ops.linear(x.to(cuda), pw, residual=res.to(cuda), rowstats=True, split_k=2)
+    finally:
+        ops.SPLITK_IN_KERNEL = True
+    assert (st3 is None or C < 128) and rel_l2(y3.float().cpu(), ref) <= REL_L2_TOL
 
 
 @pytest.mark.parametrize("rows,C,N,tile,split_k,geglu", [(96, 64, 192, 0, 1, False), (200, 320, 384, 0, 1, False),
                                                          (2048, 320, 128, 18, 1, False), (256, 1280, 640, 25, 3, False),
                                                          (130, 640, 2560, 21, 1, True), (64, 1280, 5120, 40, 1, True),
                                                          (300, 320, 1280, 9, 2, True)])
-def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, geglu, both_epilogues):
+def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, geglu, both_epilogues, both_splitk):
     """linear(LayerNorm(x)) in one launch (gamma folded into the weights, mean / rstd from the producer's row
     statistics) against F.layer_norm + F.linear in fp32 on the same bf16 x: blocks.py:782-785,808-813,821-823,41-50"""
     g = torch.Generator().manual_seed(rows * 7 + C + N)

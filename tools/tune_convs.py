@@ -79,6 +79,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cold", action="store_true", help="time every candidate with cold weights / warm activations")
     ap.add_argument("--orders", action="store_true", help="also tune the XCD-aware workgroup order (include/aptp_hip.h)")
+    ap.add_argument("--modes", action="store_true", help="also tune the split-K form: in-kernel reduction vs reduce launch")
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
@@ -99,6 +100,7 @@ def main():
         torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
     ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    counters = ops._tile_counters(dev)
     uniq = {}
     for rec in log:
         p = rec["params"]
@@ -121,31 +123,37 @@ def main():
         splits = [1, 2, 3, 4, 6, 8, 12, 16, 24]
         if args.quick:
             splits = [1, 2, 4, 8]
-        best = (t_base, base.tile, base.split_k, 0)
+        base.tile_counters = counters.data_ptr() if base.split_k > 1 else None
+        best = (t_base, base.tile, base.split_k, 0, 1)
         for tl in tiles:
             for sk in splits:
-                if sk > 1 and (nK // sk < 3 or M * p0.N * sk * 4 > ws.numel() or M >= 8192 and sk > 2):
+                if sk > 1 and (nK // sk < 3 or (M + 255) * (p0.N + 255) * sk * 4 > ws.numel() or M >= 8192 and sk > 2):
                     continue
                 for order in ((2, 3) if args.orders else (0,)):     # XCD-aware workgroup orders: weight- / activation-major
-                    q = clone_params(p0)
-                    q.tile, q.split_k, q.order = tl, sk, order
-                    q.workspace = ws.data_ptr() if sk > 1 else None
-                    us = timer(q)
-                    if us is not None and us < best[0]:
-                        best = (us, tl, sk, order)
+                    for ink in ((1, 0) if (args.modes and sk > 1) else (1,)):
+                        q = clone_params(p0)
+                        q.tile, q.split_k, q.order = tl, sk, order
+                        q.workspace = ws.data_ptr() if sk > 1 else None
+                        q.tile_counters = counters.data_ptr() if (sk > 1 and ink) else None
+                        us = timer(q)
+                        if us is not None and us < best[0]:
+                            best = (us, tl, sk, order, ink)
         if args.orders and best[3] != 0:
             # keep the legacy order honest: re-time the winner against it
             q = clone_params(p0)
             q.tile, q.split_k, q.order = best[1], best[2], 1
             q.workspace = ws.data_ptr() if best[2] > 1 else None
+            q.tile_counters = counters.data_ptr() if (best[2] > 1 and best[4]) else None
             us = min(u for u in (timer(q), timer(q)) if u is not None)
             if us < best[0]:
-                best = (us, best[1], best[2], 1)
+                best = (us, best[1], best[2], 1, best[4])
         table[key] = {"tile": best[1], "split_k": best[2], "order": best[3], "us": round(best[0], 2)}
+        if best[2] > 1:
+            table[key]["in_kernel"] = int(best[4])
         fl = u["rec"]["flops"]
         rows.append((best[0] * u["count"], key, u["count"], t_base, best, fl))
         print(f"{key:36s} x{u['count']:2d} heur {t_base:7.1f} us (t{base.tile} s{base.split_k}) -> best {best[0]:7.1f} us "
-              f"(t{best[1]} s{best[2]} o{best[3]})  {fl / best[0] / 1e6:6.1f} TF", flush=True)
+              f"(t{best[1]} s{best[2]} o{best[3]} k{best[4]})  {fl / best[0] / 1e6:6.1f} TF", flush=True)
     rows.sort(reverse=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "tune_convs" + ("_dense" if args.dense else "") + ".txt"), "w") as f:

@@ -77,6 +77,7 @@ class AttentionParams(Structure):
         ("B", c_int32), ("heads", c_int32), ("Lq", c_int32), ("Lk", c_int32),
         ("scale", c_float),
         ("lse", c_void_p),
+        ("variant", c_int32),
     ]
 
 

@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
       t = ok ? t : (u32x4){0u, 0u, 0u, 0u};
       qf[s] = __builtin_bit_cast(bf16x8, t);
     }
+    // Retire the Q loads HERE.  Otherwise their first use is the first MFMA of the key loop, behind the conditionally
+    // issued K/V prefetch of that iteration: the compiler cannot count those loads and emits s_waitcnt vmcnt(0) there,
+    // in EVERY iteration, which drains the prefetch it was meant to overlap (one exposed L2 round trip per key tile).
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(qf[s]));
   }
 
   // ---- staging coordinates ------------------------------------------------------------------------------------
@@ -78,19 +83,25 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     const int key0 = tile * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      // rows past Lk: load a clamped (valid) row unconditionally, then zero the VALUE (a pointer select against a
-      // local zero would put the staging registers in scratch)
+      // rows past Lk: load a clamped (valid) row unconditionally; store_kv zeroes the VALUE (a pointer select against a
+      // local zero would put the staging registers in scratch, and a value select HERE makes the compiler wait for the
+      // prefetch -- s_waitcnt vmcnt(0) -- right after issuing it, ahead of the MFMAs it is meant to overlap)
       const int key = key0 + krow + 32 * i;
       const int keyc = key < p.Lk ? key : p.Lk - 1;
-      const u32x4 kq = *reinterpret_cast<const u32x4*>(kp + (int64_t)keyc * p.ksl + chunk * 8);
-      kreg[i] = key < p.Lk ? kq : zero4;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kp + (int64_t)keyc * p.ksl + chunk * 8);
       const int vkey = key0 + 2 * kpair + i;
       const int vkeyc = vkey < p.Lk ? vkey : p.Lk - 1;
-      const u32x4 vq = *reinterpret_cast<const u32x4*>(vp + (int64_t)vkeyc * p.vsl + chunk * 8);
-      vreg[i] = vkey < p.Lk ? vq : zero4;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)vkeyc * p.vsl + chunk * 8);
     }
   };
-  auto store_kv = [&]() {
+  auto store_kv = [&](int tile) {
+    if (tile * 64 + 64 > p.Lk) {                 // ragged last tile (wave-uniform): zero the rows past Lk
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        kreg[i] = tile * 64 + krow + 32 * i < p.Lk ? kreg[i] : zero4;
+        vreg[i] = tile * 64 + 2 * kpair + i < p.Lk ? vreg[i] : zero4;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = krow + 32 * i;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     const int tile = t_begin + it;
     const bool active = tile < t_end;
     __syncthreads();   // everyone finished reading the previous tile
-    if (active) store_kv();
+    if (active) store_kv(tile);
     __syncthreads();
     if (!active) continue;
     if (tile + 1 < t_end) load_kv(tile + 1);
@@ -254,6 +265,249 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Staggered form of the two-group kernel (AptpAttentionParams.variant = 1; a measured negative result, see the launcher) (8 waves: waves w and w+4 share a SIMD and sweep the two halves of the key range
+// for the same 128 queries).  In attn_fwd_kernel<2> both groups run the same phase at the same time, so on every SIMD
+// the two waves' MFMAs meet in the matrix pipe and their softmax VALU work meets in the vector pipe: the per-tile cost
+// is the SUM of both (the level-64 self-attention of SD-2.1 ran at ~380 TFLOP/s).  Here every key tile is two phases
+// separated by workgroup barriers,
+//   A: S^T = K.Q^T (8 MFMAs), running maximum, exp2, row sum                      (vector-heavy)
+//   B: P -> bf16, O^T += V^T.P^T (8 MFMAs), stage the next K/V tile into the other LDS buffer, request the tile after it
+// and group 1 runs ONE phase behind group 0 (one extra barrier before its loop, one after group 0's), so a SIMD always
+// pairs a phase-A wave with a phase-B wave: the matrix work of one hides under the vector work of the other.  K/V are
+// double-buffered per group, which also removes the second barrier of the lock-step loop (a tile is staged while the
+// previous one is still being read).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const AttnK p) {
+  constexpr int KV_ELEMS = 2 * 64 * 64;                 // one K image + one V^T image
+  constexpr int MERGE_FLOATS = 256 * 34;
+  constexpr int LDS_BYTES = (4 * KV_ELEMS * 2 > MERGE_FLOATS * 4) ? 4 * KV_ELEMS * 2 : MERGE_FLOATS * 4;   // 64 KiB
+  __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+  const int grp = (int)(threadIdx.x >> 8);
+  __bf16* const kv_base = reinterpret_cast<__bf16*>(lds_raw) + grp * 2 * KV_ELEMS;    // [buffer][K | V^T]
+
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const __bf16* qp = p.q + (int64_t)b * p.qsb + (int64_t)h * 64;
+  const __bf16* kp = p.k + (int64_t)b * p.ksb + (int64_t)h * 64;
+  const __bf16* vp = p.v + (int64_t)b * p.vsb + (int64_t)h * 64;
+
+  bf16x8 qf[4];
+  {
+    const int qrow = q0 + lq;
+    const bool ok = qrow < p.Lq;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int qc = ok ? qrow : p.Lq - 1;
+      u32x4 t = *reinterpret_cast<const u32x4*>(qp + (int64_t)qc * p.qsl + 16 * s + 8 * hh);
+      t = ok ? t : (u32x4){0u, 0u, 0u, 0u};
+      qf[s] = __builtin_bit_cast(bf16x8, t);
+    }
+    // Retire the Q loads HERE.  Otherwise their first use is the first MFMA of the key loop, behind the conditionally
+    // issued K/V prefetch of that iteration: the compiler cannot count those loads and emits s_waitcnt vmcnt(0) there,
+    // in EVERY iteration, which drains the prefetch it was meant to overlap (one exposed L2 round trip per key tile).
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(qf[s]));
+  }
+
+  const int chunk = tid & 7;
+  const int krow = tid >> 3;
+  const int kpair = tid >> 3;
+  u32x4 kreg[2], vreg[2];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_kv = [&](int tile) {
+    const int key0 = tile * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = key0 + krow + 32 * i;
+      const int keyc = key < p.Lk ? key : p.Lk - 1;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kp + (int64_t)keyc * p.ksl + chunk * 8);
+      const int vkey = key0 + 2 * kpair + i;
+      const int vkeyc = vkey < p.Lk ? vkey : p.Lk - 1;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)vkeyc * p.vsl + chunk * 8);
+    }
+  };
+  auto store_kv = [&](int buf, int tile) {
+    __bf16* Ks = kv_base + buf * KV_ELEMS;
+    __bf16* Vt = Ks + 64 * 64;
+    if (tile * 64 + 64 > p.Lk) {                 // ragged last tile (wave-uniform): zero the rows past Lk
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        kreg[i] = tile * 64 + krow + 32 * i < p.Lk ? kreg[i] : zero4;
+        vreg[i] = tile * 64 + 2 * kpair + i < p.Lk ? vreg[i] : zero4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = krow + 32 * i;
+      const int sw = chunk ^ ((r >> 1) & 7);
+      *reinterpret_cast<u32x4*>(Ks + r * 64 + sw * 8) = kreg[i];
+    }
+    const int pos = vt_pos(2 * kpair);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = chunk * 8 + e;
+      const int sw = (pos >> 3) ^ ((d >> 1) & 7);
+      const uint32_t a = vreg[0][e >> 1], bb = vreg[1][e >> 1];
+      const uint32_t w = (e & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
+      *reinterpret_cast<uint32_t*>(Vt + d * 64 + sw * 8 + (pos & 7)) = w;
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles_all = (p.Lk + 63) / 64;
+  const int per_grp = (ntiles_all + 1) / 2;
+  const int t_begin = grp * per_grp;
+  const int t_end = (t_begin + per_grp < ntiles_all) ? t_begin + per_grp : ntiles_all;   // may be empty for group 1
+
+  // prologue: tile t_begin staged in buffer 0, tile t_begin + 1 requested
+  if (t_begin < t_end) { load_kv(t_begin); store_kv(0, t_begin); }
+  if (t_begin + 1 < t_end) load_kv(t_begin + 1);
+  __syncthreads();
+  if (grp == 1) __syncthreads();                 // group 1 runs one phase behind
+
+  f32x16 sacc[2];
+  for (int it = 0; it < per_grp; ++it) {         // uniform trip count: both groups meet at every barrier
+    const int tile = t_begin + it;
+    const bool active = tile < t_end;
+    const __bf16* Ks = kv_base + (it & 1) * KV_ELEMS;
+    const __bf16* Vt = Ks + 64 * 64;
+    // ---- phase A: scores and softmax ---------------------------------------------------------------------------------
+    if (active) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r_ = 32 * t + lq;
+          const int sw = (2 * s + hh) ^ ((r_ >> 1) & 7);
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + r_ * 64 + sw * 8);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[t], 0, 0, 0);
+        }
+      }
+      const int key_base = tile * 64 + 4 * hh;
+      float mx = -INFINITY;
+      if (tile * 64 + 64 <= p.Lk) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[t][r], sacc[t][r + 1]));
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key_base + 32 * t + (r & 3) + 8 * (r >> 2);
+            const float sv = key < p.Lk ? sacc[t][r] : -INFINITY;
+            sacc[t][r] = sv;
+            mx = fmaxf(mx, sv);
+          }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.c;
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][r], p.c, -m_new));
+          sacc[t][r] = pv;
+          rs += pv;
+        }
+      rs += __shfl_xor(rs, 32);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+      }
+    }
+    __syncthreads();
+    // ---- phase B: O^T += V^T . P^T, stage the next tile, request the one after -----------------------------------------
+    if (active) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[t][8 * s2 + j];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int d = 32 * u + lq;
+            const int sw = (4 * t + 2 * s2 + hh) ^ ((d >> 1) & 7);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + d * 64 + sw * 8);
+            oacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[u], 0, 0, 0);
+          }
+        }
+      }
+      // the other buffer was last read in phases A/B of the previous tile: at least one barrier ago
+      if (tile + 1 < t_end) store_kv((it + 1) & 1, tile + 1);
+      if (tile + 2 < t_end) load_kv(tile + 2);
+    }
+    __syncthreads();
+  }
+  if (grp == 0) __syncthreads();                 // pairs group 1's last barrier
+
+  // merge the two key-range groups: group 1 publishes (m, l, O) per lane, group 0 combines
+  float* mg = reinterpret_cast<float*>(lds_raw);
+  __syncthreads();
+  if (grp == 1) {
+    float* dst = mg + tid * 34;
+    dst[0] = m_run; dst[1] = l_run;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[2 + u * 16 + r] = oacc[u][r];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  {
+    const float* src = mg + tid * 34;
+    const float m1 = src[0], l1 = src[1];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);   // m_run is finite (group 0 owns >= 1 tile)
+    l_run = l_run * a0 + l1 * a1;
+    m_run = m;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[u][r] = oacc[u][r] * a0 + src[2 + u * 16 + r] * a1;
+  }
+
+  const int qrow = q0 + lq;
+  if (qrow < p.Lq) {
+    if (p.lse && hh == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run + log2f(l_run);
+    const float inv = 1.0f / l_run;
+    __bf16* op = p.o + (int64_t)b * p.osb + (int64_t)qrow * p.osl + (int64_t)h * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * u + 8 * g + 4 * hh;
+        uint2 w;
+        w.x = pack_bf16x2(oacc[u][4 * g + 0] * inv, oacc[u][4 * g + 1] * inv);
+        w.y = pack_bf16x2(oacc[u][4 * g + 2] * inv, oacc[u][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d) = w;
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream) {
@@ -276,7 +530,12 @@ extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream
   // split the key range over two wave groups when the query-parallel grid alone gives < 2 waves per SIMD
   const int64_t waves = (int64_t)grid.x * grid.y * grid.z * 4;
   const int ntiles = (p->Lk + 63) / 64;
-  if (ntiles >= 2 && waves < 2 * 1024) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, k);
+  if (ntiles >= 2 && waves < 2 * 1024) {
+    // The staggered form measured 5-10 % SLOWER than the lock-step one on MI355X (level-64 self-attention of SD-2.1:
+    // 75.9 vs 69.3 us; tools/bench_attn.py), so it is opt-in only.
+    if (p->variant == 1) hipLaunchKernelGGL(attn_fwd_pp_kernel, grid, dim3(512), 0, (hipStream_t)stream, k);     // staggered groups
+    else hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, k);                     // lock-step groups
+  }
   else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
   APTP_LAUNCH_CHECK();
   return APTP_OK;

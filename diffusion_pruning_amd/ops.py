@@ -196,6 +196,9 @@ def _tile_counters(device):
     return buf
 
 
+# AptpAttentionParams.variant for every launch (1 = staggered wave groups: A/B timing, tests of both forms)
+ATTN_VARIANT = 0
+
 # GroupNorm on the large maps: True lets the last statistics workgroup of a sample finalise mean / rstd (two launches
 # instead of three).  Measured SLOWER on MI355X (162.5 vs 164.7 steps/s: 128 tickets on one counter + the acquire cost
 # more than the 5.5 us launch they replace), so it is off; kept for tests and as a measured negative result.
@@ -298,6 +301,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if p.split_k > 1:
         if in_kernel is None:
             in_kernel = p.split_k <= 4 or explicit_split
+        if rowstats:
+            in_kernel = True        # only the workgroup that combines the slices can emit the row statistics
         if SPLITK_IN_KERNEL and in_kernel and lib.aptp_conv_gemm_tiles(ctypes.byref(p)) <= _N_COUNTERS:
             cnt = _tile_counters(x.device)
             if cnt is not None:
@@ -412,6 +417,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     p.o, p.o_stride_b, p.o_stride_l = out.data_ptr(), out.stride(0), out.stride(1)
     p.B, p.heads, p.Lq, p.Lk = B, heads, Lq, Lk
     p.scale = (1.0 / 8.0) if scale is None else scale
+    p.variant = ATTN_VARIANT
     if lse is not None:
         assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (B, heads, Lq)
         p.lse = lse.data_ptr()

@@ -198,6 +198,8 @@ typedef struct {
   int32_t B, heads, Lq, Lk;
   float scale;
   float* lse;   /* optional fp32 [B, heads, Lq]: log2-domain log-sum-exp of the scaled scores, consumed by aptp_attention_bwd */
+  int32_t variant; /* 0 = auto; 1 = run the two key-range wave groups of the 8-wave kernel one phase apart (double-buffered
+                    * K/V; measured slower than the lock-step form, kept for testing / A-B timing) */
 } AptpAttentionParams;
 
 int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream);

@@ -51,6 +51,14 @@ def both_gn_forms(ops, request):
     ops.GN_FUSED_FINALIZE = False
 
 
+@pytest.fixture(params=[0, 1], ids=["attn-lockstep", "attn-staggered"])
+def both_attn_forms(ops, request):
+    """two-group attention with the groups in lock step (default) and one phase apart"""
+    ops.ATTN_VARIANT = request.param
+    yield request.param
+    ops.ATTN_VARIANT = 0
+
+
 @pytest.fixture(params=[0, 1], ids=["epi-auto", "epi-acc-layout"])
 def both_epilogues(ops, request):
     """run a test with the coalesced (LDS-transposed) epilogue and with the accumulator-layout one"""
@@ -593,6 +601,9 @@ def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, gegl
 ATTN_CASES = [
     # B, heads, Lq, Lk
     (1, 1, 64, 64),
+    (1, 1, 128, 128),      # two key tiles: one per wave group
+    (1, 2, 200, 192),      # three key tiles: group 1 owns a single tile
+    (4, 2, 4096, 4096),    # SD-2.1 level-64 self-attention of the masked model
     (2, 2, 256, 256),
     (2, 5, 1024, 1024),
     (2, 3, 256, 77),       # cross attention, ragged key tile
@@ -602,7 +613,7 @@ ATTN_CASES = [
 
 
 @pytest.mark.parametrize("case", ATTN_CASES)
-def test_attention(ops, cuda, case):
+def test_attention(ops, cuda, case, both_attn_forms):
     B, h, Lq, Lk = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     q = _rand((B, Lq, h * 64), g).bfloat16()
@@ -618,7 +629,7 @@ def test_attention(ops, cuda, case):
     assert e <= 6e-3, f"rel-L2 {e:.3e}"   # P is rounded to bf16 before P.V (as any bf16 flash kernel does)
 
 
-def test_attention_fused_qkv_views_and_spike(ops, cuda):
+def test_attention_fused_qkv_views_and_spike(ops, cuda, both_attn_forms):
     """q/k/v as column slices of one fused buffer; one key spiked so the running max jumps mid-sequence"""
     g = torch.Generator().manual_seed(5)
     B, h, L = 2, 2, 320

@@ -19,6 +19,7 @@ struct GnK {
   const float* gamma; const float* beta; float eps; int silu;
   float* ws; int nchunk;
   float* fin;                // finalised [B, G, 2] (mean, rstd), written by gn_finalize_kernel
+  int fold_in_apply;         // 1: <= 16 coarse chunks and no finalize launch: every apply workgroup folds the partials
   int* counters;             // optional [B] arrival counters (zero on entry, left zero): the last stage-1 workgroup of a
                              // sample folds the partials itself and gn_finalize_kernel is not launched
   int TPR, RPAR;             // threads per row (= min(CO,256)), rows processed in parallel (256/TPR)
@@ -204,8 +205,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
   };
   load_rows(r0 + rl);
   if (tid < p.G) {
-    mean_s[tid] = p.fin[((int64_t)b * p.G + tid) * 2];
-    rstd_s[tid] = p.fin[((int64_t)b * p.G + tid) * 2 + 1];
+    if (p.fold_in_apply) {
+      // two-launch form: at most 16 coarse chunks, all requested at once (one L2 round trip, in flight together with the
+      // first rows of x), folded in chunk order => deterministic; 4 KB per workgroup instead of a finalize launch
+      const float2* w = reinterpret_cast<const float2*>(p.ws) + (int64_t)b * p.nchunk * p.G + tid;
+      float2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = w[(int64_t)(u < p.nchunk ? u : 0) * p.G];
+      float a = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u < p.nchunk) { a += v[u].x; a2 += v[u].y; }
+      const float inv = 1.0f / ((float)p.cg * (float)p.HW);
+      const float mean = a * inv;
+      float var = a2 * inv - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      mean_s[tid] = mean;
+      rstd_s[tid] = rsqrtf(var + p.eps);
+    } else {
+      mean_s[tid] = p.fin[((int64_t)b * p.G + tid) * 2];
+      rstd_s[tid] = p.fin[((int64_t)b * p.G + tid) * 2 + 1];
+    }
   }
   __syncthreads();
   if (!active) return;
@@ -510,10 +530,11 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   k.ws = (float*)p->workspace; k.nchunk = aptp_groupnorm_nchunk(p->HW);
   k.fin = k.ws + (int64_t)p->B * k.nchunk * p->groups * 2;
   k.counters = p->counters;
+  k.fold_in_apply = 0;
   k.TPR = CO < 256 ? CO : 256;
   k.RPAR = 256 / k.TPR;
   hipStream_t s = (hipStream_t)stream;
-  APTP_CHECK(p->variant >= 0 && p->variant <= 2, "groupnorm: variant %d", p->variant);
+  APTP_CHECK(p->variant >= 0 && p->variant <= 3, "groupnorm: variant %d", p->variant);
   // group-owner single launch: gpb = fewest groups whose channels fill whole 16-byte chunks
   int gpb = 1;
   while ((gpb * k.cg) % 8 != 0) gpb *= 2;   // cg * 8 is always a multiple of 8, so gpb <= 8
@@ -545,6 +566,14 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
     }
   }
   APTP_CHECK(p->variant != 2, "groupnorm: variant 2 does not fit (HW %d, cg %d: slab too large for one workgroup's registers)", p->HW, k.cg);
+  if (p->variant == 3) {
+    // two launches: coarse statistics chunks (>= 256 rows each, at most 16) that every apply workgroup folds itself
+    int nc = p->HW / 256;
+    nc = nc < 1 ? 1 : (nc > 16 ? 16 : nc);
+    k.nchunk = nc;
+    k.fold_in_apply = 1;
+    k.counters = nullptr;
+  }
   dim3 grid1(k.nchunk, p->B);
   int nchunk2 = p->HW / 16;   // >= 16 rows per apply workgroup, up to 8 resident workgroups per CU
   if (nchunk2 < 1) nchunk2 = 1;
@@ -552,11 +581,11 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   dim3 grid2(nchunk2, p->B);
   if (CO <= 256) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);
-    if (!k.counters) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
+    if (!k.counters && !k.fold_in_apply) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(256), 0, s, k);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<2>, grid1, dim3(256), 0, s, k);
-    if (!k.counters) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
+    if (!k.counters && !k.fold_in_apply) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(256), 0, s, k);
   }
   APTP_LAUNCH_CHECK();

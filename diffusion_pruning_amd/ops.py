@@ -196,6 +196,12 @@ def _tile_counters(device):
     return buf
 
 
+# AptpGroupNormParams.variant used when the caller asks for "auto" (0).  0 = the library's own choice (small maps in one
+# launch, large maps in three).  3 (large maps in two launches: <= 16 coarse statistics chunks folded by the apply
+# workgroups) measured much SLOWER on MI355X (149.5 vs 167.4 steps/s: 64 statistics workgroups cannot stream a level-64
+# map fast enough), so it stays opt-in.
+GN_DEFAULT_VARIANT = 0
+
 # AptpAttentionParams.variant for every launch (1 = staggered wave groups: A/B timing, tests of both forms)
 ATTN_VARIANT = 0
 
@@ -372,7 +378,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
         return out, ws
     else:
         ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
-    p.variant = variant
+    p.variant = variant if variant else GN_DEFAULT_VARIANT
     p.workspace = ws.data_ptr()
     cnt = _tile_counters(x.device) if (GN_FUSED_FINALIZE and B <= _N_COUNTERS) else None
     if cnt is not None:

@@ -158,7 +158,8 @@ typedef struct {
   int32_t silu;
   void* workspace;
   /* 0 = auto; 1 = three launches (stats, finalise, apply): the only form that fills the workspace partials
-   * aptp_groupnorm_bwd consumes; 2 = one launch, each workgroup owning whole groups of one sample (small maps). */
+   * aptp_groupnorm_bwd consumes; 2 = one launch, each workgroup owning whole groups of one sample (small maps);
+   * 3 = two launches: at most 16 coarse statistics chunks, folded by every apply workgroup (no finalise launch). */
   int32_t variant;
   /* optional, three-launch form only: >= B int32 words, ZERO on entry and left zero.  The last statistics workgroup of
    * each sample then folds the partials itself (write-through partial stores, one agent-scope acquire) and the

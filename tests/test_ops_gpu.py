@@ -449,7 +449,7 @@ GN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", GN_CASES)
 def test_groupnorm(ops, cuda, case, variant, both_gn_forms):
     """variant 1 = three launches (the form the backward consumes), 2 = one launch with group-owning workgroups,
@@ -477,7 +477,7 @@ def test_groupnorm(ops, cuda, case, variant, both_gn_forms):
         assert float(got[..., C:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_groupnorm_strided_view_and_determinism(ops, cuda, variant, both_gn_forms):
     """input = channel slice of a wider (concat) buffer, output into a slice too; two runs are bit-identical"""
     B, H, W, C, G = 2, 16, 16, 640, 32

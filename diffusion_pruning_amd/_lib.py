@@ -42,8 +42,13 @@ class ConvGemmParams(Structure):
         ("rowstat_out", c_void_p), ("rowstat_slots", c_int32),
         ("ln_stats", c_void_p), ("ln_slots", c_int32),
         ("ln_colsum", c_void_p), ("ln_eps", c_float), ("ln_C", c_int32),
+        ("colstat_out", c_void_p), ("colstat_ld", c_int32),
         ("tile_counters", c_void_p), ("epilogue", c_int32),
     ]
+
+
+class GroupNormColStats(Structure):
+    _fields_ = [("stats", c_void_p), ("ld", c_int32), ("rows_per_block", c_int32), ("C", c_int32)]
 
 
 class GroupNormParams(Structure):
@@ -55,6 +60,7 @@ class GroupNormParams(Structure):
         ("eps", c_float), ("silu", c_int32),
         ("workspace", c_void_p), ("variant", c_int32),
         ("counters", c_void_p),
+        ("colstats", GroupNormColStats * 2),
     ]
 
 
@@ -156,6 +162,7 @@ EXPORTS = [
     ("aptp_conv_gemm_suggest_split_k", c_int, [POINTER(ConvGemmParams)]),
     ("aptp_conv_gemm_rowstat_slots", c_int, [POINTER(ConvGemmParams)]),
     ("aptp_conv_gemm_tiles", c_int, [POINTER(ConvGemmParams)]),
+    ("aptp_conv_gemm_colstat_rows", c_int, [POINTER(ConvGemmParams)]),
     ("aptp_groupnorm", c_int, [POINTER(GroupNormParams), c_void_p]),
     ("aptp_groupnorm_nchunk", c_int, [c_int]),
     ("aptp_groupnorm_workspace_bytes", c_int64, [POINTER(GroupNormParams)]),

@@ -49,6 +49,7 @@ struct KParams {
   int64_t ws_ld;            // workspace row stride (floats)
   int order;                // workgroup -> tile order (decode_block): 0 legacy, 1 weight-major, 2 activation-major
   int* counters;            // in-kernel split-K: one arrival counter per output tile (zero on entry, left zero)
+  float* cstat_out; int cstat_ld;   // per-(row block, channel) (sum, sumsq) of the stored outputs: GroupNorm statistics
   int epi16;                // 1: bf16 output (and residual / depth_in) rows are 16-byte aligned -> coalesced epilogue
   float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
   const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
@@ -373,6 +374,9 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
   const int c0 = (GEGLU ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN)) + lc8 * 8;   // this lane's first logical column
   const bool lane_on = lrow < RPP && c0 < p.Nout;
   __bf16* const yb = reinterpret_cast<__bf16*>(p.y);
+  float cs[8], cs2[8];            // per-channel (sum, sumsq) over this lane's rows (p.cstat_out)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cs2[e] = 0.f; }
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const int mbase = m0 + wm * WTM + i * 16;
@@ -415,6 +419,9 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
         }
       }
     }
+    // (cross-lane exchange through LDS inside one wave: tell the compiler, see the column-statistics staging below)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // transposed domain: + residual, depth lerp, round, 16-byte store, row statistics
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -448,6 +455,14 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
 #else
       if (on) *reinterpret_cast<uint4*>(yb + (int64_t)m2 * p.ldy + c0) = o;
 #endif
+      if constexpr (!GEGLU) {
+        if (p.cstat_out && on) {   // statistics of the values as stored (bf16-rounded): what the GroupNorm will read
+          float f[8];
+          unpack_bf16x8(o, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cs[e] += f[e]; cs2[e] += f[e] * f[e]; }
+        }
+      }
       if constexpr (POW2) {
         if (p.rstat_out) {       // statistics of the values as stored (bf16-rounded): what the consumer will read
           float f[8], s0 = 0.f, s1 = 0.f;
@@ -463,6 +478,53 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
             reinterpret_cast<float2*>(p.rstat_out)[(int64_t)(tn * WN + wn) * p.M + m2] = q;
           }
         }
+      }
+    }
+  }
+  if constexpr (!GEGLU && WL >= 32) {
+    if (p.cstat_out) {
+      // GroupNorm statistics for the consumer of y: per channel, the sum / sum of squares over the WTM rows this wave
+      // stored.  Lanes with the same 8-column chunk (lrow = 0..RPP-1) are folded through the wave's LDS slice, sums first,
+      // then squares (RPP*WL <= 512 floats fit the 16 x (WL+4) slice); one (sum, sumsq) per channel goes to row block
+      // m0/WTM + wm of cstat_out.  Fixed order: deterministic.
+      static_assert(RPP * WL <= 16 * PITCH, "column-statistics staging");
+      float tot[2][(WL + 63) / 64];
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        if (lrow < RPP) {
+          float* dst = buf + lrow * WL + lc8 * 8;
+          if (ph == 0) {
+            *reinterpret_cast<float4*>(dst) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(cs2[0], cs2[1], cs2[2], cs2[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(cs2[4], cs2[5], cs2[6], cs2[7]);
+          }
+        }
+        // Lanes exchange data through LDS here without a workgroup barrier (one wave, in-order LDS): the compiler must
+        // still be told.  Without the fence it reasons per thread -- "a lane that skipped the store reads what it read in
+        // the previous phase" -- and reuses the phase-0 loads for the lanes with lrow >= RPP (seen: sumsq == sum there).
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < (WL + 63) / 64; ++q) {
+          const int t = lane + 64 * q;
+          float a = 0.f;
+          if (t < WL) {
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) a += buf[r * WL + t];
+          }
+          tot[ph][q] = a;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      const int cw0 = n0 + wn * WTN;
+      float2* dstg = reinterpret_cast<float2*>(p.cstat_out) + (int64_t)(m0 / WTM + wm) * p.cstat_ld;
+#pragma unroll
+      for (int q = 0; q < (WL + 63) / 64; ++q) {
+        const int t = lane + 64 * q;
+        if (t < WL && cw0 + t < p.Nout) dstg[cw0 + t] = make_float2(tot[0][q], tot[1][q]);
       }
     }
   }
@@ -1144,15 +1206,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
   else epilogue_quad<false>(p, m, rc, n, h, h, st);
 }
 
-struct TileCfg { int bm, bn, wn; };   // tile extents and the wave grid's N extent (launch table below)
-const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 2}, {128, 160, 2}, {64, 128, 2}, {64, 160, 2}, {128, 64, 2}, {64, 64, 2},
-                          {128, 128, 2}, {128, 160, 2}, {64, 128, 2}, {64, 160, 2}, {128, 64, 2}, {64, 64, 2},    // 7..12: LDS-DMA, 2 stages
-                          {128, 128, 2}, {128, 160, 2}, {64, 128, 2}, {64, 160, 2}, {128, 64, 2}, {64, 64, 2},    // 13..18: LDS-DMA, 3 stages
-                          {128, 160, 2}, {256, 160, 2}, {128, 128, 4}, {256, 128, 2},                             // 19..22: LDS-DMA, 8 waves
-                          {64, 160, 2}, {64, 128, 2}, {64, 64, 2}, {128, 64, 2}, {128, 128, 2},                   // 23..27: LDS-DMA, 4 stages
-                          {128, 160, 2}, {128, 160, 2}, {128, 128, 4}, {128, 128, 4}, {256, 128, 2},              // 28..32: 8 waves, 3/4-stage ring
-                          {128, 160, 2}, {128, 160, 2}, {128, 128, 4}, {128, 128, 4}, {64, 160, 2}, {64, 128, 4}, // 33..38: 8 waves, ping-pong
-                          {64, 160, 2}, {128, 64, 2}, {256, 128, 2}, {128, 256, 4}};                              // 39..42
+struct TileCfg { int bm, bn, wn, nw; };   // tile extents, the wave grid's N extent and the wave count (launch table below)
+const TileCfg kTiles[] = {
+    {0, 0, 0, 0}, {128, 128, 2, 4}, {128, 160, 2, 4}, {64, 128, 2, 4}, {64, 160, 2, 4}, {128, 64, 2, 4},
+    {64, 64, 2, 4}, {128, 128, 2, 4}, {128, 160, 2, 4}, {64, 128, 2, 4}, {64, 160, 2, 4}, {128, 64, 2, 4},
+    {64, 64, 2, 4}, {128, 128, 2, 4}, {128, 160, 2, 4}, {64, 128, 2, 4}, {64, 160, 2, 4}, {128, 64, 2, 4},
+    {64, 64, 2, 4}, {128, 160, 2, 8}, {256, 160, 2, 8}, {128, 128, 4, 8}, {256, 128, 2, 8}, {64, 160, 2, 4},
+    {64, 128, 2, 4}, {64, 64, 2, 4}, {128, 64, 2, 4}, {128, 128, 2, 4}, {128, 160, 2, 8}, {128, 160, 2, 8},
+    {128, 128, 4, 8}, {128, 128, 4, 8}, {256, 128, 2, 8}, {128, 160, 2, 8}, {128, 160, 2, 8}, {128, 128, 4, 8},
+    {128, 128, 4, 8}, {64, 160, 2, 8}, {64, 128, 4, 8}, {64, 160, 2, 8}, {128, 64, 2, 8}, {256, 128, 2, 8},
+    {128, 256, 4, 8}};
 constexpr int kNumTiles = 43;
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
@@ -1230,6 +1293,7 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
                               ((uintptr_t)p->ln_stats % 8) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
              "conv_gemm: folded LayerNorm needs ln_colsum [N], ln_slots > 0, ln_C > 0 and a 1x1 filter");
   k.counters = p->tile_counters;
+  k.cstat_out = p->colstat_out; k.cstat_ld = p->colstat_ld;
   k.epi16 = !p->out_f32 && p->ldy % 8 == 0 && ((uintptr_t)p->y % 16) == 0 && nout % 8 == 0 &&
             (!p->residual || (p->ldres % 8 == 0 && ((uintptr_t)p->residual % 16) == 0)) &&
             (!p->depth || (p->lddin % 8 == 0 && ((uintptr_t)p->depth_in % 16) == 0));
@@ -1301,6 +1365,13 @@ extern "C" int aptp_conv_gemm_tiles(const AptpConvGemmParams* p) {
   return (int)(((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((p->N + kTiles[t].bn - 1) / kTiles[t].bn));
 }
 
+extern "C" int aptp_conv_gemm_colstat_rows(const AptpConvGemmParams* p) {
+  if (!p) return 0;
+  const int t = pick_tile(p, p->B * p->Hout * p->Wout);
+  if (t <= 0 || t >= kNumTiles) return 0;
+  return kTiles[t].bm / (kTiles[t].nw / kTiles[t].wn);      // WTM: rows of one wave's block
+}
+
 extern "C" int aptp_conv_gemm_rowstat_slots(const AptpConvGemmParams* p) {
   if (!p) return 0;
   const int t = pick_tile(p, p->B * p->Hout * p->Wout);
@@ -1341,6 +1412,15 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     if ((k.split_k != 1 && !k.counters) || k.rstat_slots != slots) {
       aptp_set_error("conv_gemm: rowstat_out needs split_k == 1 (or the in-kernel reduction) and rowstat_slots == aptp_conv_gemm_rowstat_slots() (%d), got split_k %d, slots %d",
                      slots, k.split_k, k.rstat_slots);
+      return APTP_EINVAL;
+    }
+  }
+  if (k.cstat_out) {
+    const int wtm = kTiles[t].bm / (kTiles[t].nw / kTiles[t].wn), wtn = kTiles[t].bn / kTiles[t].wn;
+    if (!k.epi16 || k.act == APTP_ACT_GEGLU || (k.split_k != 1 && !k.counters) || k.HW % wtm != 0 || wtn < 32 ||
+        k.cstat_ld < k.Nout || ((uintptr_t)k.cstat_out % 8) != 0) {
+      aptp_set_error("conv_gemm: colstat_out needs the coalesced bf16 epilogue, no GEGLU, split_k == 1 (or the in-kernel reduction), "
+                     "Hout*Wout %% %d == 0 (aptp_conv_gemm_colstat_rows) and colstat_ld >= N", wtm);
       return APTP_EINVAL;
     }
   }

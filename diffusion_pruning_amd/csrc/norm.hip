@@ -63,6 +63,61 @@ __device__ __forceinline__ void gn_finalize_sample(const GnK& p, int b, int tid)
 
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnK p) { gn_finalize_sample(p, blockIdx.x, threadIdx.x); }
 
+// Finalise from PRODUCER-emitted column statistics (aptp_conv_gemm colstat_out): the tensor is one or two channel
+// segments (a skip-concat has two producers), each with per-(row block, channel) (sum, sumsq) partials.  Grid (G, B):
+// one workgroup folds the cg channels x row blocks of its (sample, group) in a fixed order and writes (mean, rstd).
+struct GnSeg { const float2* st; int ld, rows, C; };
+struct GnCols { GnSeg seg[2]; int B, HW, G, cg; float eps; float* fin; };
+
+__global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const GnCols p) {
+  __shared__ float red[2][256];
+  const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+  const int c_lo = g * p.cg, c_hi = c_lo + p.cg;
+  float a = 0.f, a2 = 0.f;
+  int cbase = 0;
+#pragma unroll
+  for (int sI = 0; sI < 2; ++sI) {
+    const GnSeg sg = p.seg[sI];
+    if (sg.st) {
+      const int lo = c_lo > cbase ? c_lo : cbase, hi = c_hi < cbase + sg.C ? c_hi : cbase + sg.C;   // channels of this group here
+      const int nch = hi - lo;
+      if (nch > 0) {
+        const int nrb = p.HW / sg.rows;                       // row blocks per sample
+        const float2* base = sg.st + (int64_t)b * nrb * sg.ld + (lo - cbase);
+        const int cnt = nrb * nch;
+        for (int i0 = tid; i0 < cnt; i0 += 1024) {            // 4 partials in flight per thread
+          float2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u < cnt ? i0 + 256 * u : i0;
+            const int rb = i / nch, c = i - rb * nch;
+            v[u] = base[(int64_t)rb * sg.ld + c];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < cnt) { a += v[u].x; a2 += v[u].y; }
+        }
+      }
+      cbase += sg.C;
+    }
+  }
+  red[0][tid] = a; red[1][tid] = a2;
+  __syncthreads();
+#pragma unroll
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float inv = 1.0f / ((float)p.cg * (float)p.HW);
+    const float mean = red[0][0] * inv;
+    float var = red[1][0] * inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    p.fin[((int64_t)b * p.G + g) * 2] = mean;
+    p.fin[((int64_t)b * p.G + g) * 2 + 1] = rsqrtf(var + p.eps);
+  }
+}
+
 template <int NP>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
   __shared__ float red[2][2048 * NP];   // [sum|sumsq][RPAR * TPR*8*NP]  (RPAR*TPR <= 256)
@@ -539,7 +594,7 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   int gpb = 1;
   while ((gpb * k.cg) % 8 != 0) gpb *= 2;   // cg * 8 is always a multiple of 8, so gpb <= 8
   const int tpr = gpb * k.cg / 8;
-  if (p->variant != 1 && tpr <= 32) {
+  if (p->variant != 1 && tpr <= 32 && p->colstats[0].stats == nullptr) {
     GnG q;
     q.x = k.x; q.ldx = k.ldx; q.y = k.y; q.ldy = k.ldy; q.B = k.B; q.HW = k.HW; q.C = k.C; q.G = k.G; q.cg = k.cg;
     q.gamma = k.gamma; q.beta = k.beta; q.eps = k.eps; q.silu = k.silu;
@@ -575,17 +630,35 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
     k.counters = nullptr;
   }
   dim3 grid1(k.nchunk, p->B);
+  const bool from_cols = p->colstats[0].stats != nullptr;
+  if (from_cols) {
+    GnCols c;
+    int ctot = 0;
+    for (int i = 0; i < 2; ++i) {
+      const AptpGroupNormColStats& d = p->colstats[i];
+      c.seg[i].st = reinterpret_cast<const float2*>(d.stats); c.seg[i].ld = d.ld; c.seg[i].rows = d.rows_per_block; c.seg[i].C = d.C;
+      if (d.stats) {
+        APTP_CHECK(d.rows_per_block > 0 && p->HW % d.rows_per_block == 0 && d.C > 0 && d.ld >= d.C && ((uintptr_t)d.stats % 8) == 0,
+                   "groupnorm: bad colstats segment %d (rows_per_block must divide HW, ld >= C)", i);
+        ctot += d.C;
+      }
+    }
+    APTP_CHECK(ctot == p->C, "groupnorm: colstats segments cover %d channels, tensor has %d", ctot, p->C);
+    c.B = p->B; c.HW = p->HW; c.G = p->groups; c.cg = p->C / p->groups; c.eps = p->eps; c.fin = k.fin;
+    k.counters = nullptr; k.fold_in_apply = 0;
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(p->groups, p->B), dim3(256), 0, s, c);
+  }
   int nchunk2 = p->HW / 16;   // >= 16 rows per apply workgroup, up to 8 resident workgroups per CU
   if (nchunk2 < 1) nchunk2 = 1;
   if (nchunk2 > 256) nchunk2 = 256;
   dim3 grid2(nchunk2, p->B);
   if (CO <= 256) {
-    hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);
-    if (!k.counters && !k.fold_in_apply) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
+    if (!from_cols) hipLaunchKernelGGL(gn_stats_kernel<1>, grid1, dim3(256), 0, s, k);
+    if (!from_cols && !k.counters && !k.fold_in_apply) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(256), 0, s, k);
   } else {
-    hipLaunchKernelGGL(gn_stats_kernel<2>, grid1, dim3(256), 0, s, k);
-    if (!k.counters && !k.fold_in_apply) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
+    if (!from_cols) hipLaunchKernelGGL(gn_stats_kernel<2>, grid1, dim3(256), 0, s, k);
+    if (!from_cols && !k.counters && !k.fold_in_apply) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p->B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(256), 0, s, k);
   }
   APTP_LAUNCH_CHECK();

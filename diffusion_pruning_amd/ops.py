@@ -225,13 +225,60 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+# GroupNorm statistics emitted by the GEMM that produces a tensor (AptpConvGemmParams.colstat_out) travel with the
+# tensor: they are recorded on its root storage owner (the tensor itself, or the concat buffer it is a channel slice of)
+# under the view's storage offset, so the consumer finds them through any permute / reshape view, and the two halves of
+# a skip-concat buffer keep separate records.  COLSTATS_MIN_HW: only maps large enough for GroupNorm's multi-launch form.
+COLSTATS = True
+COLSTATS_MIN_HW = 1024
+
+
+def _root(t: torch.Tensor) -> torch.Tensor:
+    return t._base if t._base is not None else t
+
+
+def _colstats_drop(out: torch.Tensor):
+    d = getattr(_root(out), "_aptp_colstats", None)
+    if d:
+        d.pop(out.storage_offset(), None)
+
+
+def _colstats_put(out: torch.Tensor, stats: torch.Tensor, rows_per_block: int):
+    root = _root(out)
+    d = getattr(root, "_aptp_colstats", None)
+    if d is None:
+        d = {}
+        root._aptp_colstats = d
+    d[out.storage_offset()] = (stats, rows_per_block, out.shape[3], (out.shape[0], out.shape[1] * out.shape[2]), _ld(out))
+
+
+def _colstats_get(x: torch.Tensor, C: int):
+    """producer statistics covering the NHWC view x (C real channels, the rest zero padding): one record, or two adjacent
+    ones (skip-concat); returns [(stats, rows_per_block, channels used), ...] or None"""
+    d = getattr(_root(x), "_aptp_colstats", None)
+    if not d:
+        return None
+    segs, off, left, pad = [], x.storage_offset(), x.shape[3], x.shape[3] - C
+    while left > 0 and len(segs) < 2:
+        rec = d.get(off)
+        if rec is None or rec[3] != (x.shape[0], x.shape[1] * x.shape[2]) or rec[4] != _ld(x) or rec[2] > left:
+            return None
+        segs.append([rec[0], rec[1], rec[2]])
+        off += rec[2]
+        left -= rec[2]
+    if left != 0 or segs[-1][2] <= pad:
+        return None
+    segs[-1][2] -= pad
+    return segs
+
+
 def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None, ups: int = 0,
               out: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
               colgate: Optional[torch.Tensor] = None, gate_group: int = 0, act: int = ACT_NONE,
               corr: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
               out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0,
-              rowstats: bool = False, ln=None):
+              rowstats: bool = False, ln=None, colstats: bool = False):
     """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites.
     rowstats: also emit the per-row (sum, sumsq) partials of y a following folded LayerNorm needs; returns (y, stats)
     with stats fp32 [slots, M, 2], or (y, None) when this launch is split along K (the caller then normalises with
@@ -253,6 +300,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if out is None:
         out = torch.empty(B, Hout, Wout, nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     else:
+        _colstats_drop(out)          # whatever statistics were recorded for this memory describe its old contents
         if tuple(out.shape) != (B, Hout, Wout, nout) or out.stride(3) != 1:
             raise ValueError(f"conv_gemm: out shape {tuple(out.shape)} != {(B, Hout, Wout, nout)}")
         if out.dtype != (torch.float32 if out_f32 else torch.bfloat16):
@@ -307,8 +355,13 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if p.split_k > 1:
         if in_kernel is None:
             in_kernel = p.split_k <= 4 or explicit_split
-        if rowstats:
-            in_kernel = True        # only the workgroup that combines the slices can emit the row statistics
+        # only the workgroup that combines the slices can emit row / column statistics.  Column statistics are worth the
+        # in-kernel form up to 2 slices (beyond that it loses more than the GroupNorm statistics pass it saves: measured
+        # +8 us on the 4-slice level-32 convs against a 6.5 us pass + a kernel boundary)
+        want_cols = colstats and COLSTATS and Hout * Wout >= COLSTATS_MIN_HW and act != ACT_GEGLU and not out_f32 \
+            and (in_kernel or p.split_k <= 2)
+        if rowstats or want_cols:
+            in_kernel = True
         if SPLITK_IN_KERNEL and in_kernel and lib.aptp_conv_gemm_tiles(ctypes.byref(p)) <= _N_COUNTERS:
             cnt = _tile_counters(x.device)
             if cnt is not None:
@@ -320,6 +373,17 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         slots = lib.aptp_conv_gemm_rowstat_slots(ctypes.byref(p))
         stats = torch.empty(slots, B * Hout * Wout, 2, dtype=torch.float32, device=x.device)
         p.rowstat_out, p.rowstat_slots = stats.data_ptr(), slots
+    cstats = None
+    if colstats and COLSTATS and Hout * Wout >= COLSTATS_MIN_HW and act != ACT_GEGLU and not out_f32 \
+            and (p.split_k == 1 or cnt is not None) and _ld(out) % 8 == 0 and out.data_ptr() % 16 == 0 and nout % 8 == 0 \
+            and (residual is None or (_ld(residual) % 8 == 0 and residual.data_ptr() % 16 == 0)) \
+            and (depth_in is None or (_ld(depth_in) % 8 == 0 and depth_in.data_ptr() % 16 == 0)) and p.epilogue == 0:
+        rpb = lib.aptp_conv_gemm_colstat_rows(ctypes.byref(p))
+        if rpb > 0 and (Hout * Wout) % rpb == 0:
+            M = B * Hout * Wout
+            nblk = (M + rpb - 1) // rpb + 16          # (+ the padding blocks of the last, partial tile)
+            cstats = torch.empty(nblk, nout, 2, dtype=torch.float32, device=x.device)
+            p.colstat_out, p.colstat_ld = cstats.data_ptr(), nout
     if ln is not None:
         ln_stats, ln_eps = ln
         if pw.ln_colsum is None:
@@ -331,9 +395,11 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     elif pw.ln_colsum is not None:
         raise ValueError("conv_gemm: weights with a folded LayerNorm need ln=(stats, eps)")
     _lib.check(lib.aptp_conv_gemm(ctypes.byref(p), _stream()), "aptp_conv_gemm")
+    if cstats is not None:
+        _colstats_put(out, cstats, rpb)
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * pw.KH * pw.KW * pw.Cin,
-                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt)})
+                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats)})
     return (out, stats) if rowstats else out
 
 
@@ -380,6 +446,11 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
         ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
     p.variant = variant if variant else GN_DEFAULT_VARIANT
     p.workspace = ws.data_ptr()
+    segs = _colstats_get(x, C) if (COLSTATS and variant == 0 and H * W >= COLSTATS_MIN_HW) else None
+    if segs is not None:
+        for i, (st, rpb, cseg) in enumerate(segs):
+            p.colstats[i].stats, p.colstats[i].ld, p.colstats[i].rows_per_block, p.colstats[i].C = st.data_ptr(), st.shape[1], rpb, cseg
+        p.variant = 1                       # the multi-launch skeleton (statistics pass replaced by the finalise)
     cnt = _tile_counters(x.device) if (GN_FUSED_FINALIZE and B <= _N_COUNTERS) else None
     if cnt is not None:
         p.counters = cnt.data_ptr()

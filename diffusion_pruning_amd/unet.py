@@ -345,13 +345,15 @@ class ResnetBlock2DWidthGated(nn.Module):
         gate_kw = {}
         if not pl["compact"] and self.gate.hard_uniform() is None:
             gate_kw = dict(colgate=self._gate_dev(dev), gate_group=self.out_channels // self.groups)
-        h = ops.conv_gemm(a1, pl["w1"], rowbias=rowbias, **gate_kw)
+        # (colstats: the GEMM that produces a GroupNorm input also emits its per-channel statistics; ops.groupnorm finds
+        # them with the tensor and skips its own statistics pass on the large maps)
+        h = ops.conv_gemm(a1, pl["w1"], rowbias=rowbias, colstats=True, **gate_kw)
         a2 = ops.groupnorm(h, pl["g2"], pl["b2"], pl["k_live"], self.eps, True, C=pl["c_live"])
         sc = x if pl["wsc"] is None else ops.conv_gemm(x, pl["wsc"], pad=0)
         dkw = {}
         if self.depth_gated and d_hard is None:
             dkw = dict(depth=d_vec, depth_in=x_in)
-        out = ops.conv_gemm(a2, pl["w2"], corr=pl["corr"], residual=sc, out=dst, **dkw)
+        out = ops.conv_gemm(a2, pl["w2"], corr=pl["corr"], residual=sc, out=dst, colstats=True, **dkw)
         return _nchw(out)
 
     def _gate_dev(self, dev):
@@ -794,7 +796,7 @@ class Transformer2DModelWidthGated(nn.Module):
         dkw = {}
         if self.depth_gated and d_hard is None:
             dkw = dict(depth=d_vec, depth_in=x_tok)
-        out = ops.linear(h, pl["proj_out"], residual=x_tok, out=None if dst is None else dst.reshape(B, P, C), **dkw)
+        out = ops.linear(h, pl["proj_out"], residual=x_tok, out=None if dst is None else dst.reshape(B, P, C), colstats=True, **dkw)
         return self._ret(_nchw(out.reshape(B, H, W, C) if dst is None else dst), return_dict)
 
     @staticmethod
@@ -884,7 +886,7 @@ class Downsample2D(nn.Module):
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), stride=2, pad=1))
         Ho, Wo = (x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1
         dst = _take_dst(self, x.shape[0], Ho, Wo, self._pw.N, x.device)
-        return _nchw(ops.conv_gemm(x, self._pw, stride=2, pad=1, out=dst))
+        return _nchw(ops.conv_gemm(x, self._pw, stride=2, pad=1, out=dst, colstats=True))
 
     def _get_bwd(self, dev):
         def get():
@@ -919,7 +921,7 @@ class Upsample2D(nn.Module):
             from . import autograd as AG
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), ups=1))
         dst = _take_dst(self, x.shape[0], 2 * x.shape[1], 2 * x.shape[2], self._pw.N, x.device)
-        return _nchw(ops.conv_gemm(x, self._pw, ups=1, out=dst))
+        return _nchw(ops.conv_gemm(x, self._pw, ups=1, out=dst, colstats=True))
 
     def _get_bwd(self, dev):
         def get():
@@ -1569,7 +1571,7 @@ class UNet2DConditionModelGated(nn.Module):
         x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
         x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
         conv_in_dst = self._register_cat_slots(B, x.shape[1], x.shape[2], misc["conv_in"].N, dev)
-        h = _nchw(ops.conv_gemm(x, misc["conv_in"], out=conv_in_dst))
+        h = _nchw(ops.conv_gemm(x, misc["conv_in"], out=conv_in_dst, colstats=True))
 
         # 3. down
         down_block_res_samples = (h,)

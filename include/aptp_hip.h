@@ -100,6 +100,14 @@ typedef struct {
   const float* ln_colsum;
   float ln_eps;
   int32_t ln_C;
+  /* GroupNorm statistics emitted by the producer (F.group_norm of ResnetBlock2D.norm1 / norm2, Transformer2DModel.norm,
+   * conv_norm_out: blocks.py:296-301,350-359,1227; unet_2d_conditional.py:1718): per channel, fp32 (sum, sumsq) of the
+   * bf16 values stored for each block of R = aptp_conv_gemm_colstat_rows() consecutive output rows, colstat_out
+   * [ceil(M/R) rounded up to whole tiles, colstat_ld, 2].  Needs Hout*Wout % R == 0 (a block never straddles samples),
+   * a bf16 non-GEGLU output with 16-byte aligned rows, split_k == 1 or the in-kernel reduction.  aptp_groupnorm consumes
+   * them through AptpGroupNormParams.colstats and skips its own statistics pass. */
+  float* colstat_out;
+  int32_t colstat_ld;
   int32_t* tile_counters; /* optional, split_k > 1: >= aptp_conv_gemm_tiles() int32 words, ZERO on entry and left zero: the
                            * K-slices are then combined inside the launch by the last-arriving workgroup of each output tile
                            * (one agent-scope release / acquire per tile, slabs re-read in slice order: deterministic) and no
@@ -131,6 +139,8 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);
+/* rows per statistics block of colstat_out for the tile the launch will use */
+int aptp_conv_gemm_colstat_rows(const AptpConvGemmParams* p);
 /* output tiles of the launch (size of tile_counters) */
 int aptp_conv_gemm_tiles(const AptpConvGemmParams* p);
 /* number of row-statistics slots a launch of this problem writes per row (N-tiles x wave columns of the tile it will use) */
@@ -149,6 +159,12 @@ int aptp_conv_gemm_suggest_split_k(const AptpConvGemmParams* p);
  * workspace: aptp_groupnorm_workspace_bytes() = fp32 [B, nchunk, groups, 2] (sum, sumsq) partials, nchunk =
  * aptp_groupnorm_nchunk(HW), followed by the finalised [B, groups, 2] (mean, rstd).
  */
+/* one channel segment of producer-emitted statistics (AptpConvGemmParams.colstat_out) */
+typedef struct {
+  const float* stats;       /* [B*HW/rows_per_block (+ padding blocks), ld, 2] or NULL */
+  int32_t ld, rows_per_block, C;
+} AptpGroupNormColStats;
+
 typedef struct {
   const void* x; int64_t ldx;   /* bf16 [B*HW, >=C] */
   void* y; int64_t ldy;         /* bf16 [B*HW, >=C] */
@@ -165,6 +181,10 @@ typedef struct {
    * each sample then folds the partials itself (write-through partial stores, one agent-scope acquire) and the
    * finalise launch is skipped: two launches instead of three. */
   int32_t* counters;
+  /* optional: the statistics were emitted by the GEMM(s) that produced x -- one segment, or two for a skip-concat
+   * (segment 0 = channels [0, C0), segment 1 = [C0, C)).  The statistics pass over x is skipped: a (groups x B)-workgroup
+   * finalise from the partials, then the apply pass (two launches, x read once). */
+  AptpGroupNormColStats colstats[2];
 } AptpGroupNormParams;
 
 int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream);

@@ -219,6 +219,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
   gn_finalize_sample(p, b, tid);
 }
 
+// gamma / beta of 8 consecutive channels starting at c0 (a multiple of 8): two 16-byte loads each when the whole octet is
+// inside [0, C) -- 4 wave instructions instead of 16 four-byte ones; these kernels stream a few KB per workgroup, so the
+// coefficient loads were the majority of their vector-memory instructions -- element-wise at a ragged tail
+__device__ __forceinline__ void load_affine8(const float* gamma, const float* beta, int c0, int C, bool on, float ga[8], float be[8]) {
+  if (on && c0 + 8 <= C) {
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+    be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = on && c0 + e < C;
+      ga[e] = ok ? gamma[c0 + e] : 0.f;
+      be[e] = ok ? beta[c0 + e] : 0.f;
+    }
+  }
+}
+
 template <int NP>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
   __shared__ float mean_s[32], rstd_s[32];
@@ -232,13 +251,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
 #pragma unroll
   for (int pg = 0; pg < NP; ++pg) {
     const int o = ot + pg * 256;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = o * 8 + e;
-      const bool ok = active && o < p.CO && c < p.C;
-      ga[pg][e] = ok ? p.gamma[c] : 0.f;
-      be[pg][e] = ok ? p.beta[c] : 0.f;
-    }
+    load_affine8(p.gamma, p.beta, o * 8, p.C, active && o < p.CO, ga[pg], be[pg]);
   }
   const int r0 = (int)(((int64_t)p.HW * chunk) / gridDim.x), r1 = (int)(((int64_t)p.HW * (chunk + 1)) / gridDim.x);
   const __bf16* xb = p.x + ((int64_t)b * p.HW) * p.ldx;
@@ -373,6 +386,10 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
       const_cast<__bf16*>(p.x + ((int64_t)b * p.HW) * p.ldx), 0, (int)(((int64_t)(p.HW - 1) * p.ldx + ((p.C + 7) / 8) * 8) * 2), 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const unsigned col_b = (unsigned)(c0 + ot * 8) * 2u, ld_b = (unsigned)p.ldx * 2u;
+  // affine coefficients of this thread's channels, requested together with the slab (they used to be fetched element by
+  // element AFTER the reduction: a second dependent memory round trip in a kernel that is one latency chain)
+  float gaf[8], bef[8];
+  load_affine8(p.gamma, p.beta, c0 + ot * 8, c1, active, gaf, bef);
   u32x4 q[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -451,9 +468,9 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
     for (int e = 0; e < 8; ++e) {
       const int c = c0 + ot * 8 + e;
       if (c < c1) {
-        const float k = rstd_s[lg] * p.gamma[c];
+        const float k = rstd_s[lg] * gaf[e];
         sc[e] = k;
-        sh[e] = p.beta[c] - mean_s[lg] * k;
+        sh[e] = bef[e] - mean_s[lg] * k;
         valid |= 1u << e;
       } else {
         sc[e] = 0.f; sh[e] = 0.f;

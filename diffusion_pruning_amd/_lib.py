@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libaptp_hip.so")
+# (APTP_LIB=<file> loads another build of the same ABI: A/B timing of kernel changes on one box)
+LIB_PATH = os.environ.get("APTP_LIB") or os.path.join(_HERE, "csrc", "libaptp_hip.so")
 
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x160, TILE_64x128, TILE_64x160, TILE_128x64, TILE_64x64 = range(7)

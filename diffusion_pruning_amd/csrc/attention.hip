@@ -11,6 +11,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // (HIP's uint4 struct makes value selects go through scratch)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct AttnK {
   const __bf16* q; int64_t qsb, qsl;
@@ -37,10 +38,10 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
   // one LDS array: per group a [key][d] K image (chunks XOR-swizzled by (key>>1)&7) and a [d][vt_pos(key)] V^T image
   // (chunks XOR-swizzled by (d>>1)&7); reused at the end for the group merge (NG == 2)
   constexpr int KV_ELEMS = 2 * 64 * 64;
-  constexpr int MERGE_FLOATS = (NG == 2) ? 256 * 34 : 0;
+  constexpr int MERGE_FLOATS = (NG >= 2) ? (NG / 2) * 256 * 34 : 0;     // one merge round: the upper half publishes
   constexpr int LDS_BYTES = (NG * KV_ELEMS * 2 > MERGE_FLOATS * 4) ? NG * KV_ELEMS * 2 : MERGE_FLOATS * 4;
   __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
-  const int grp = (NG == 2) ? (int)(threadIdx.x >> 8) : 0;
+  const int grp = (NG >= 2) ? (int)(threadIdx.x >> 8) : 0;
   __bf16* Ks = reinterpret_cast<__bf16*>(lds_raw) + grp * KV_ELEMS;
   __bf16* Vt = Ks + 64 * 64;
 
@@ -79,8 +80,22 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
   u32x4 kreg[2], vreg[2];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+  // per-thread row pointers of the tile being prefetched, advanced by 64 keys per tile (the per-tile 64-bit address
+  // arithmetic was 34 of the loop's ~280 vector instructions, and the loop is bound by vector issue)
+  const __bf16* kptr[2];
+  const __bf16* vptr[2];
   auto load_kv = [&](int tile) {
     const int key0 = tile * 64;
+    if (key0 + 64 <= p.Lk) {                   // full tile (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        kreg[i] = *reinterpret_cast<const u32x4*>(kptr[i]);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vptr[i]);
+        kptr[i] += 64 * p.ksl;
+        vptr[i] += 64 * p.vsl;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // rows past Lk: load a clamped (valid) row unconditionally; store_kv zeroes the VALUE (a pointer select against a
@@ -131,6 +146,11 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
   const int per_grp = (ntiles_all + NG - 1) / NG;
   const int t_begin = grp * per_grp;
   const int t_end = (t_begin + per_grp < ntiles_all) ? t_begin + per_grp : ntiles_all;   // may be empty for grp 1
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    kptr[i] = kp + (int64_t)(t_begin * 64 + krow + 32 * i) * p.ksl + chunk * 8;
+    vptr[i] = vp + (int64_t)(t_begin * 64 + 2 * kpair + i) * p.vsl + chunk * 8;
+  }
   if (t_begin < t_end) load_kv(t_begin);
   for (int it = 0; it < per_grp; ++it) {       // uniform trip count: both groups meet at every barrier
     const int tile = t_begin + it;
@@ -162,10 +182,12 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     // raw scores (c > 0), and the accumulator is only rescaled when some lane's maximum moved.
     float mx = -INFINITY;
     if (tile * 64 + 64 <= p.Lk) {              // full tile (wave-uniform): no key masking
+      // v_max3_f32 directly: fmaxf() on MFMA results makes hipcc canonicalise every operand first (v_max_f32 x, x),
+      // 56 instructions for 32 scores instead of 16
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[t][r], sacc[t][r + 1]));
+        for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sacc[t][r]), "v"(sacc[t][r + 1]));
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -182,15 +204,23 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     // (raw v_exp_f32: arguments are <= 0, so the range scaling / denormal fix-up exp2f() wraps around the instruction --
     // compare, two selects, an add and an ldexp per score -- buys nothing; results below 2^-126 flush to zero)
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
-    float rs = 0.f;
+    // scale + shift and the row sum on packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32: half the instructions)
+    f32x2 rs2 = {0.f, 0.f};
+    const f32x2 c2 = {p.c, p.c}, nm2 = {-m_new, -m_new};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][r], p.c, -m_new));   // masked keys: -inf * c - m = -inf -> 0
-        sacc[t][r] = pv;
-        rs += pv;
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 x2 = {sacc[t][r], sacc[t][r + 1]};
+        x2 = __builtin_elementwise_fma(x2, c2, nm2);               // masked keys: -inf * c - m = -inf -> 0
+        f32x2 pv2;
+        pv2[0] = __builtin_amdgcn_exp2f(x2[0]);
+        pv2[1] = __builtin_amdgcn_exp2f(x2[1]);
+        sacc[t][r] = pv2[0];
+        sacc[t][r + 1] = pv2[1];
+        rs2 += pv2;
       }
+    float rs = rs2[0] + rs2[1];
     rs += __shfl_xor(rs, 32);
     l_run = l_run * alpha + rs;
     m_run = m_new;
@@ -220,30 +250,38 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     }
   }
 
-  if (NG == 2) {
-    // merge the two key-range groups: group 1 publishes (m, l, O) per lane, group 0 combines
+  if (NG >= 2) {
+    // merge the key-range groups pairwise (a tree: NG/2 groups publish (m, l, O) per lane, their partners combine, ...)
     float* mg = reinterpret_cast<float*>(lds_raw);
     __syncthreads();                            // all K/V tile reads are done; the LDS array is free
-    if (grp == 1) {
-      float* dst = mg + tid * 34;
-      dst[0] = m_run; dst[1] = l_run;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+    for (int half = NG / 2; half >= 1; half >>= 1) {
+      if (grp >= half && grp < 2 * half) {
+        float* dst = mg + ((grp - half) * 256 + tid) * 34;
+        dst[0] = m_run; dst[1] = l_run;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[2 + u * 16 + r] = oacc[u][r];
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[2 + u * 16 + r] = oacc[u][r];
+      }
+      __syncthreads();
+      if (grp < half) {
+        const float* src = mg + (grp * 256 + tid) * 34;
+        const float m1 = src[0], l1 = src[1];
+        const float m = fmaxf(m_run, m1);
+        // a group that owns no key tile carries m = -inf, l = 0, O = 0 and must weigh 0 (never exp2(-inf + inf))
+        const float a0 = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m);
+        const float a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
+        l_run = l_run * a0 + l1 * a1;
+        m_run = m;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[u][r] = oacc[u][r] * a0 + src[2 + u * 16 + r] * a1;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (grp == 1) return;
-    const float* src = mg + tid * 34;
-    const float m1 = src[0], l1 = src[1];
-    const float m = fmaxf(m_run, m1);
-    const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);      // m_run is finite (group 0 always owns >= 1 tile)
-    l_run = l_run * a0 + l1 * a1;
-    m_run = m;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[u][r] = oacc[u][r] * a0 + src[2 + u * 16 + r] * a1;
+    if (grp != 0) return;
   }
 
   // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------------
@@ -279,6 +317,7 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
 // double-buffered per group, which also removes the second barrier of the lock-step loop (a tile is staged while the
 // previous one is still being read).
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool STAGGER>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const AttnK p) {
   constexpr int KV_ELEMS = 2 * 64 * 64;                 // one K image + one V^T image
   constexpr int MERGE_FLOATS = 256 * 34;
@@ -375,7 +414,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const AttnK p) {
   if (t_begin < t_end) { load_kv(t_begin); store_kv(0, t_begin); }
   if (t_begin + 1 < t_end) load_kv(t_begin + 1);
   __syncthreads();
-  if (grp == 1) __syncthreads();                 // group 1 runs one phase behind
+  if (STAGGER && grp == 1) __syncthreads();      // group 1 runs one phase behind
 
   f32x16 sacc[2];
   for (int it = 0; it < per_grp; ++it) {         // uniform trip count: both groups meet at every barrier
@@ -437,7 +476,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const AttnK p) {
           for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
       }
     }
-    __syncthreads();
+    if (STAGGER) __syncthreads();                // (!STAGGER: double-buffered lock-step form, ONE barrier per key tile)
     // ---- phase B: O^T += V^T . P^T, stage the next tile, request the one after -----------------------------------------
     if (active) {
 #pragma unroll
@@ -462,7 +501,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const AttnK p) {
     }
     __syncthreads();
   }
-  if (grp == 0) __syncthreads();                 // pairs group 1's last barrier
+  if (STAGGER && grp == 0) __syncthreads();      // pairs group 1's last barrier
 
   // merge the two key-range groups: group 1 publishes (m, l, O) per lane, group 0 combines
   float* mg = reinterpret_cast<float*>(lds_raw);
@@ -533,8 +572,13 @@ extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream
   if (ntiles >= 2 && waves < 2 * 1024) {
     // The staggered form measured 5-10 % SLOWER than the lock-step one on MI355X (level-64 self-attention of SD-2.1:
     // 75.9 vs 69.3 us; tools/bench_attn.py), so it is opt-in only.
-    if (p->variant == 1) hipLaunchKernelGGL(attn_fwd_pp_kernel, grid, dim3(512), 0, (hipStream_t)stream, k);     // staggered groups
-    else hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, k);                     // lock-step groups
+    if (p->variant == 1) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, k);     // staggered groups
+    // double-buffered K/V, ONE barrier per key tile: -10 % on long key ranges (65.7 vs 73.2 us at level 64), no gain below
+    else if (p->variant == 4 || (p->variant == 0 && ntiles >= 32))
+      hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, k);
+    else if (p->variant == 2)      // four key-range groups (16 waves): measured slower (90 vs 71 us at level 64), opt-in only
+      hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(1024), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, k);                     // two lock-step groups (also variant 3)
   }
   else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
   APTP_LAUNCH_CHECK();

@@ -220,7 +220,10 @@ typedef struct {
   float scale;
   float* lse;   /* optional fp32 [B, heads, Lq]: log2-domain log-sum-exp of the scaled scores, consumed by aptp_attention_bwd */
   int32_t variant; /* 0 = auto; 1 = run the two key-range wave groups of the 8-wave kernel one phase apart (double-buffered
-                    * K/V; measured slower than the lock-step form, kept for testing / A-B timing) */
+                    * K/V; measured slower than the lock-step form, kept for testing / A-B timing); 2 = force four key-range
+                    * groups (16 waves); 3 = force two lock-step groups with single-buffered K/V (two barriers per key tile);
+                    * 4 = force two lock-step groups with double-buffered K/V (one barrier per key tile; auto from 32 key
+                    * tiles) */
 } AptpAttentionParams;
 
 int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream);

@@ -51,9 +51,9 @@ def both_gn_forms(ops, request):
     ops.GN_FUSED_FINALIZE = False
 
 
-@pytest.fixture(params=[0, 1], ids=["attn-lockstep", "attn-staggered"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["attn-auto", "attn-staggered", "attn-4groups", "attn-2groups", "attn-dbuf"])
 def both_attn_forms(ops, request):
-    """two-group attention with the groups in lock step (default) and one phase apart"""
+    """key-split attention in its forms: auto, two groups one phase apart, four groups, two lock-step groups"""
     ops.ATTN_VARIANT = request.param
     yield request.param
     ops.ATTN_VARIANT = 0

@@ -44,7 +44,9 @@ class ConvGemmParams(Structure):
         ("ln_stats", c_void_p), ("ln_slots", c_int32),
         ("ln_colsum", c_void_p), ("ln_eps", c_float), ("ln_C", c_int32),
         ("colstat_out", c_void_p), ("colstat_ld", c_int32),
-        ("tile_counters", c_void_p), ("epilogue", c_int32),
+        ("tile_counters", c_void_p),
+        ("x2", c_void_p), ("ldx2", c_int64), ("Cin2", c_int32), ("cin2_pad", c_int32),
+        ("epilogue", c_int32),
     ]
 
 

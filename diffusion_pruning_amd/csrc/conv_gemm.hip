@@ -35,7 +35,10 @@ struct KParams {
   int B, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, ups;   // ups: right-shift applied to gather coordinates (0/1)
   int zins;                 // 1: zero-insertion upsample (odd coordinates read zero) instead of nearest
   int HinE, WinE;           // effective (upsampled) input extent
-  const __bf16* w; int N; int ncc; int nK; int64_t Ktot;   // ncc = cin_pad/64, nK = taps*ncc
+  const __bf16* w; int N; int ncc; int nK; int64_t Ktot;   // ncc = cin_pad/64, nK = taps*ncc + ncc2
+  // optional second operand: one more K-segment after the filter taps, a 1x1 "tap" at the output pixel over x2's channels
+  // (the resnet's conv_shortcut fused into conv2: K = 9*C_mid + C_in)
+  const __bf16* x2; int64_t ldx2; int Cin2; int ncc2; int x2_bytes;
   const float* bias; const float* rowbias; int ld_rowbias;
   const float* colgate; int gate_group, gate_B;
   int act;
@@ -659,9 +662,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   // zero padding, the M/N/Cin tails and the predicated-off prefetch without any divergent control flow.
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x2src = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x2 ? p.x2 : p.x), 0, p.x2 ? p.x2_bytes : 0, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const int chunk = tid & 7, rowbase = tid >> 3;
-  int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS];
+  int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS], a_m[A_PASS];
 #pragma unroll
   for (int i = 0; i < A_PASS; ++i) {
     const int m = m0 + rowbase + 32 * i;
@@ -671,8 +675,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
       a_iy0[i] = oy * p.stride - p.pad;
       a_ix0[i] = ox * p.stride - p.pad;
       a_pix0[i] = b * p.Hin * p.Win;
+      a_m[i] = m;
     } else {
-      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0;   // always out of range => zero rows
+      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0; a_m[i] = -1;   // always out of range => zero rows
     }
   }
   unsigned b_off[B_PASS];
@@ -682,25 +687,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
     b_off[i] = n < p.N ? (unsigned)(((int64_t)n * p.Ktot + chunk * 8) * 2) : OOB;
   }
 
-  // K-iteration state of the NEXT tile to load
+  // K-iteration state of the NEXT tile to load (l_ky == KH: the x2 segment after the filter taps)
+  const int nk_taps = p.KH * p.KW * p.ncc;
   int l_kt = kt_begin;
   int l_tap = kt_begin / p.ncc;
   int l_cc = kt_begin - l_tap * p.ncc;
   int l_ky = l_tap / p.KW;
   int l_kx = l_tap - l_ky * p.KW;
+  if (kt_begin >= nk_taps) { l_ky = p.KH; l_kx = 0; l_cc = kt_begin - nk_taps; }
 
   u32x4 ra[A_PASS], rb[B_PASS];
 
   auto load_tile = [&](bool pred) {
     const int c = l_cc * BK + chunk * 8;
-    const bool c_ok = pred && c < p.Cin;
+    if (l_ky >= p.KH) {                       // wave-uniform: second operand, the output pixel itself
+      const bool c_ok = pred && c < p.Cin2;
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) {
-      int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
-      const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE && !(p.zins & (iy | ix));
-      iy >>= p.ups; ix >>= p.ups;
-      const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31 (checked on the host)
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ok ? off : OOB, 0, 0);
+      for (int i = 0; i < A_PASS; ++i) {
+        const unsigned off = ((unsigned)a_m[i] * (unsigned)p.ldx2 + (unsigned)c) * 2u;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(x2src, (c_ok && a_m[i] >= 0) ? off : OOB, 0, 0);
+      }
+    } else {
+      const bool c_ok = pred && c < p.Cin;
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) {
+        int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
+        const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE && !(p.zins & (iy | ix));
+        iy >>= p.ups; ix >>= p.ups;
+        const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31 (checked on the host)
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ok ? off : OOB, 0, 0);
+      }
     }
     const unsigned koff = (unsigned)l_kt * (BK * 2);
 #pragma unroll
@@ -709,9 +725,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
     }
     // advance
     ++l_kt;
-    if (++l_cc == p.ncc) {
+    if (++l_cc == (l_ky >= p.KH ? p.ncc2 : p.ncc)) {
       l_cc = 0;
-      if (++l_kx == p.KW) { l_kx = 0; ++l_ky; }
+      if (++l_kx == p.KW || l_ky >= p.KH) { l_kx = 0; ++l_ky; }
     }
   };
 
@@ -864,7 +880,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   const char* zpage = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
   const char* xbase = reinterpret_cast<const char*>(p.x) + schunk * 16;
   const bool tail_bad = ((p.ncc - 1) * BK + schunk * 8) >= p.Cin;   // this lane's chunk of the last channel step is padding
-  int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS];
+  const bool tail_bad2 = ((p.ncc2 - 1) * BK + schunk * 8) >= p.Cin2;  // same for the x2 segment
+  const char* x2base = reinterpret_cast<const char*>(p.x2) + schunk * 16;
+  int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS], a_m[A_PASS];
 #pragma unroll
   for (int i = 0; i < A_PASS; ++i) {
     const int m = m0 + rowbase + RPP * i;
@@ -874,18 +892,31 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
       a_iy0[i] = oy * p.stride - p.pad;
       a_ix0[i] = ox * p.stride - p.pad;
       a_pix0[i] = b * p.Hin * p.Win;
+      a_m[i] = m;
     } else {
-      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0;       // rows past M: every tap is "padding"
+      a_iy0[i] = -100000; a_ix0[i] = -100000; a_pix0[i] = 0; a_m[i] = -1;   // rows past M: every tap is "padding"
     }
   }
 
+  // (l_ky == KH: the x2 segment after the filter taps, see KParams)
+  const int nk_taps = p.KH * p.KW * p.ncc;
   int l_tap = kt_begin / p.ncc;
   int l_cc = kt_begin - l_tap * p.ncc;
   int l_ky = l_tap / p.KW;
   int l_kx = l_tap - l_ky * p.KW;
+  if (kt_begin >= nk_taps) { l_ky = p.KH; l_kx = 0; l_cc = kt_begin - nk_taps; }
 
   const char* a_ptr[A_PASS];
   auto set_tap = [&](int cc0) {          // (re)compute the row pointers of the current tap, positioned at channel step cc0
+    if (l_ky >= p.KH) {                  // wave-uniform: the second operand, read at the output pixel itself
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) {
+        const uint64_t va = reinterpret_cast<uint64_t>(x2base) + ((unsigned)a_m[i] * (unsigned)p.ldx2) * 2u + (unsigned)cc0 * (BK * 2);   // < 2^31
+        const uint64_t vz = reinterpret_cast<uint64_t>(zpage) + (unsigned)cc0 * (BK * 2);
+        a_ptr[i] = reinterpret_cast<const char*>((a_m[i] >= 0 && p.x2) ? va : vz);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
@@ -913,11 +944,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   bool abl_first = true;
 #endif
   auto issue_tile = [&](int buf) {
-    const bool last_cc = l_cc == p.ncc - 1;
+    const bool seg2 = l_ky >= p.KH;                                 // wave-uniform
+    const bool last_cc = l_cc == (seg2 ? p.ncc2 : p.ncc) - 1;
+    const bool tb = seg2 ? tail_bad2 : tail_bad;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       if (wave * 8 + RPP * i < BM) {                               // wave-uniform: the last pass may be partial
-        const char* src = (last_cc && tail_bad) ? zpage : a_ptr[i];
+        const char* src = (last_cc && tb) ? zpage : a_ptr[i];
         __bf16* dst = As + (buf * BM + wave * 8 + RPP * i) * BK;   // wave-uniform; lane l lands at dst + l*16 B
 #if APTP_ABLATE & 1
         if (abl_first)
@@ -937,9 +970,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
       }
       b_ptr[i] += BK * 2;
     }
-    if (++l_cc == p.ncc) {               // next tap (wave-uniform branch)
+    if (++l_cc == (seg2 ? p.ncc2 : p.ncc)) {   // next tap (wave-uniform branch)
       l_cc = 0;
-      if (++l_kx == p.KW) { l_kx = 0; ++l_ky; }
+      if (++l_kx == p.KW || seg2) { l_kx = 0; ++l_ky; }
       set_tap(0);
     }
 #if APTP_ABLATE & 1
@@ -1283,7 +1316,18 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   k.B = p->B; k.Hin = p->Hin; k.Win = p->Win; k.Cin = p->Cin; k.Hout = p->Hout; k.Wout = p->Wout;
   k.KH = p->KH; k.KW = p->KW; k.stride = p->stride; k.pad = p->pad; k.ups = sh; k.zins = p->ups == 2 ? 1 : 0;
   k.HinE = HinE; k.WinE = WinE;
-  k.w = (const __bf16*)p->w; k.N = p->N; k.ncc = p->cin_pad / BK; k.nK = p->KH * p->KW * k.ncc;
+  k.x2 = (const __bf16*)p->x2; k.ldx2 = p->ldx2; k.Cin2 = p->x2 ? p->Cin2 : 0; k.ncc2 = p->x2 ? p->cin2_pad / BK : 0; k.x2_bytes = 0;
+  if (p->x2) {
+    APTP_CHECK(p->Cin2 > 0 && p->Cin2 % 8 == 0 && p->cin2_pad % BK == 0 && p->cin2_pad >= p->Cin2 && p->cin2_pad < p->Cin2 + BK,
+               "conv_gemm: x2 needs Cin2 (%d) a positive multiple of 8 and cin2_pad (%d) == ceil(Cin2/64)*64", p->Cin2, p->cin2_pad);
+    APTP_CHECK(p->ldx2 % 8 == 0 && p->ldx2 >= p->Cin2 && ((uintptr_t)p->x2 % 16) == 0, "conv_gemm: x2 row stride / alignment");
+    APTP_CHECK(p->stride == 1 && p->ups == 0 && p->Hout == p->Hin && p->Wout == p->Win,
+               "conv_gemm: x2 (second operand read at the output pixel) needs a stride-1, same-size convolution");
+    const int64_t x2b = (((int64_t)p->B * p->Hout * p->Wout - 1) * p->ldx2 + p->Cin2) * 2;
+    APTP_CHECK(x2b < (1ll << 31), "conv_gemm: x2 larger than 2 GiB");
+    k.x2_bytes = (int)x2b;
+  }
+  k.w = (const __bf16*)p->w; k.N = p->N; k.ncc = p->cin_pad / BK; k.nK = p->KH * p->KW * k.ncc + k.ncc2;
   k.Ktot = (int64_t)k.nK * BK;
   k.bias = p->bias; k.rowbias = p->rowbias; k.ld_rowbias = p->ld_rowbias;
   k.colgate = p->colgate; k.gate_group = p->gate_group; k.gate_B = p->gate_B;
@@ -1422,7 +1466,7 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   hipStream_t s = (hipStream_t)stream;
   int t = pick_tile(p, k.M);
   if (t < 0 || t >= kNumTiles) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
-  if (t >= APTP_TILE_DMA_128x128 && p->cin_pad * 2 > 8064) {
+  if (t >= APTP_TILE_DMA_128x128 && (p->cin_pad * 2 > 8064 || (p->x2 && p->cin2_pad * 2 > 8064))) {
     // the LDS-DMA variants stream padding lanes from an 8 KiB zero page that must cover one channel row
     aptp_set_error("conv_gemm: LDS-DMA tiles need Cin <= 4032 (got cin_pad %d)", p->cin_pad);
     return APTP_EINVAL;

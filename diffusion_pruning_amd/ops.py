@@ -65,10 +65,13 @@ class PackedWeight:
     KW: int
     geglu: bool = False
     ln_colsum: Optional[torch.Tensor] = None   # fp32 [N]: row sums of the bf16 weights when a LayerNorm is folded in
+    Cin2: int = 0                              # second-operand K-segment (pack_weight_cat): channels, padded channels
+    cin2_pad: int = 0
+    cin_pad_: int = 0                          # cin_pad of the main segment when w is the flat [N, 1, Ktot] of a cat pack
 
     @property
     def cin_pad(self) -> int:
-        return self.w.shape[2]
+        return self.cin_pad_ or self.w.shape[2]
 
 
 def round_up(v: int, m: int) -> int:
@@ -150,10 +153,35 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out_idx
     return PackedWeight(packed.contiguous(), None if bias is None else bias.contiguous(), N, cin_live, KH, KW, geglu, colsum)
 
 
+def pack_weight_cat(pw: PackedWeight, w2: torch.Tensor, bias2: Optional[torch.Tensor] = None, *,
+                    in_idx: Optional[torch.Tensor] = None) -> PackedWeight:
+    """Append a second-operand K-segment (include/aptp_hip.h, x2) to packed conv weights: w2 [N_logical, Cin2] is the 1x1
+    convolution applied to x2 at the output pixel (the resnet's conv_shortcut fused into conv2), bias2 is added to the
+    bias.  Rows follow pw's rows (w2 is zero-padded to pw.N rows)."""
+    assert not pw.geglu and pw.ln_colsum is None and pw.Cin2 == 0
+    dev = pw.w.device
+    w2 = w2.to(device=dev, dtype=torch.float32).reshape(w2.shape[0], -1)
+    if in_idx is not None:
+        w2 = w2[:, in_idx.to(dev)]
+    n_live, c2 = w2.shape
+    assert n_live <= pw.N
+    c2_live = round_up(c2, 8)
+    c2_pad = round_up(c2_live, BK)
+    ext = torch.zeros(pw.N, c2_pad, dtype=torch.bfloat16, device=dev)
+    ext[:n_live, :c2] = w2.to(torch.bfloat16)
+    flat = torch.cat([pw.w.reshape(pw.N, -1), ext], 1).reshape(pw.N, 1, -1).contiguous()
+    bias = pw.bias
+    if bias2 is not None:
+        b2 = torch.zeros(pw.N, dtype=torch.float32, device=dev)
+        b2[:n_live] = bias2.to(device=dev, dtype=torch.float32)
+        bias = b2 if bias is None else bias + b2
+    return PackedWeight(flat, bias, pw.N, pw.Cin, pw.KH, pw.KW, False, None, c2_live, c2_pad, pw.cin_pad)
+
+
 _ws_cache = {}
 
-def tuning_key(M, N, Cin, taps, stride, ups, geglu) -> str:
-    return f"M{M}_N{N}_C{Cin}_T{taps}_s{stride}u{ups}g{int(bool(geglu))}"
+def tuning_key(M, N, Cin, taps, stride, ups, geglu, Cin2: int = 0) -> str:
+    return f"M{M}_N{N}_C{Cin}_T{taps}_s{stride}u{ups}g{int(bool(geglu))}" + (f"x{Cin2}" if Cin2 else "")
 
 
 def _load_tuning():
@@ -278,7 +306,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               corr: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
               out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0,
-              rowstats: bool = False, ln=None, colstats: bool = False):
+              rowstats: bool = False, ln=None, colstats: bool = False, x2: Optional[torch.Tensor] = None):
     """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites.
     rowstats: also emit the per-row (sum, sumsq) partials of y a following folded LayerNorm needs; returns (y, stats)
     with stats fp32 [slots, M, 2], or (y, None) when this launch is split along K (the caller then normalises with
@@ -310,6 +338,13 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.B, p.Hin, p.Win, p.Cin, p.Hout, p.Wout = B, Hin, Win, Cx, Hout, Wout
     p.KH, p.KW, p.stride, p.pad, p.ups = pw.KH, pw.KW, stride, pad, ups
     p.w, p.N, p.cin_pad = pw.w.data_ptr(), pw.N, pw.cin_pad
+    if (x2 is not None) != (pw.Cin2 > 0):
+        raise ValueError("conv_gemm: x2 goes with weights packed by pack_weight_cat (and only with them)")
+    if x2 is not None:
+        _check_act(x2, "conv_gemm x2")
+        if tuple(x2.shape) != (B, Hout, Wout, pw.Cin2):
+            raise ValueError(f"conv_gemm: x2 shape {tuple(x2.shape)} != {(B, Hout, Wout, pw.Cin2)}")
+        p.x2, p.ldx2, p.Cin2, p.cin2_pad = x2.data_ptr(), _ld(x2), pw.Cin2, pw.cin2_pad
     p.bias = None if pw.bias is None else pw.bias.data_ptr()
     if rowbias is not None:
         assert rowbias.dtype == torch.float32 and rowbias.dim() == 2 and rowbias.shape[0] == B and rowbias.stride(1) == 1
@@ -342,7 +377,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     in_kernel = None                 # split-K form: tuned per shape; untuned shapes combine in-kernel up to 4 slices
     explicit_split = split_k is not None
     if split_k is None and tile == 0:
-        tuned = TUNING.get(tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU))
+        tuned = TUNING.get(tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2))
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
             in_kernel = bool(tuned.get("in_kernel", 0))
@@ -398,8 +433,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if cstats is not None:
         _colstats_put(out, cstats, rpb)
     if LAUNCH_LOG is not None:
-        LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * pw.KH * pw.KW * pw.Cin,
-                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats)})
+        LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * (pw.KH * pw.KW * pw.Cin + pw.Cin2),
+                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats, x2)})
     return (out, stats) if rowstats else out
 
 

@@ -349,10 +349,18 @@ class ResnetBlock2DWidthGated(nn.Module):
         # them with the tensor and skips its own statistics pass on the large maps)
         h = ops.conv_gemm(a1, pl["w1"], rowbias=rowbias, colstats=True, **gate_kw)
         a2 = ops.groupnorm(h, pl["g2"], pl["b2"], pl["k_live"], self.eps, True, C=pl["c_live"])
-        sc = x if pl["wsc"] is None else ops.conv_gemm(x, pl["wsc"], pad=0)
         dkw = {}
         if self.depth_gated and d_hard is None:
             dkw = dict(depth=d_vec, depth_in=x_in)
+        if pl["wsc"] is not None and FUSE_SHORTCUT:
+            # conv2(a2) + conv_shortcut(x) (blocks.py:362-369) as ONE GEMM: the 1x1 shortcut is one more K-segment of
+            # conv2 (K = 9*C_mid + C_in, second operand x), so its output never round-trips through memory
+            pw = pl.get("w2sc")
+            if pw is None:
+                pw = pl["w2sc"] = ops.pack_weight_cat(pl["w2"], self.conv_shortcut.weight.detach(), self.conv_shortcut.bias.detach())
+            out = ops.conv_gemm(a2, pw, x2=x, corr=pl["corr"], out=dst, colstats=True, **dkw)
+            return _nchw(out)
+        sc = x if pl["wsc"] is None else ops.conv_gemm(x, pl["wsc"], pad=0)
         out = ops.conv_gemm(a2, pl["w2"], corr=pl["corr"], residual=sc, out=dst, colstats=True, **dkw)
         return _nchw(out)
 
@@ -1086,6 +1094,8 @@ class UpBlock2DWidthHalfDepthGated(CrossAttnUpBlock2DWidthHalfDepthGated):
                          resnet_groups, resnet_eps, with_attention=False)
 
 
+# APTP_FUSE_SHORTCUT=0 keeps the resnets' 1x1 conv_shortcut as its own launch (A/B timing, debugging)
+FUSE_SHORTCUT = os.environ.get("APTP_FUSE_SHORTCUT", "1") != "0"
 # APTP_FOLD_LN=0 keeps the three LayerNorms of a transformer block as stand-alone kernels (A/B timing, debugging)
 FOLD_LN = os.environ.get("APTP_FOLD_LN", "1") != "0"
 CAT_STATS = {"views": 0, "copies": 0}     # how the skip-concats of the forwards so far were realised (tests / tools)

@@ -112,6 +112,14 @@ typedef struct {
                            * K-slices are then combined inside the launch by the last-arriving workgroup of each output tile
                            * (one agent-scope release / acquire per tile, slabs re-read in slice order: deterministic) and no
                            * reduce kernel is launched; words may be shared by launches of one stream */
+  /* optional second operand: one more K-segment after the KH*KW filter taps, read AT the output pixel (a 1x1 "tap") over
+   * the Cin2 channels of x2 [B, Hout, Wout, >=Cin2] (row stride ldx2); the packed weights are then
+   * [N][KH*KW*cin_pad + cin2_pad].  Fuses ResnetBlock2D.conv_shortcut (blocks.py:364-367,570-573) into conv2:
+   * conv2(h) + conv_shortcut(x) is one GEMM with K = 9*C_mid + C_in, the shortcut never round-trips through memory and
+   * its bias is added to conv2's.  Needs stride 1, no upsampling, Hout == Hin, Wout == Win. */
+  const void* x2;
+  int64_t ldx2;
+  int32_t Cin2, cin2_pad;
   int32_t epilogue;     /* 0 = auto (coalesced 16-byte stores through an LDS transpose when y / residual / depth_in rows are
                          * 16-byte aligned), 1 = force the accumulator-layout epilogue (testing / tuning) */
 } AptpConvGemmParams;

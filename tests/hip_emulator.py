@@ -18,18 +18,23 @@ def _bf(x):
 
 def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colgate=None, gate_group=0, act=ACT_NONE,
               corr=None, residual=None, depth=None, depth_in=None, out_f32=False, split_k=None, tile=0,
-              rowstats=False, ln=None, colstats=False):
+              rowstats=False, ln=None, colstats=False, x2=None):
     B, H, W, C = x.shape
     assert C == pw.Cin and x.dtype == torch.bfloat16
     if pad is None:
         pad = pw.KH // 2
     if pw.geglu:
         act = ACT_GEGLU
-    w = pw.w.float()[:, :, :C].reshape(pw.N, pw.KH, pw.KW, C).permute(0, 3, 1, 2)
+    wflat = pw.w.float().reshape(pw.N, -1)
+    w = wflat[:, :pw.KH * pw.KW * pw.cin_pad].reshape(pw.N, pw.KH * pw.KW, pw.cin_pad)[:, :, :C].reshape(pw.N, pw.KH, pw.KW, C).permute(0, 3, 1, 2)
     xin = x.float().permute(0, 3, 1, 2)
     if ups:
         xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
     y = F.conv2d(xin, w, None, stride=stride, padding=pad)
+    assert (x2 is not None) == (pw.Cin2 > 0)
+    if x2 is not None:          # second-operand K-segment: a 1x1 convolution of x2 at the output pixel
+        w2 = wflat[:, pw.KH * pw.KW * pw.cin_pad:][:, :x2.shape[3]]
+        y = y + F.conv2d(x2.float().permute(0, 3, 1, 2), w2[:, :, None, None])
     if ln is not None:          # LayerNorm folded into the packed weights (include/aptp_hip.h, ln_stats)
         stats, eps = ln
         assert pw.ln_colsum is not None and pw.KH == 1

@@ -109,14 +109,14 @@ def main():
     uniq = {}
     for rec in log:
         p = rec["params"]
-        key = ops.tuning_key(p.B * p.Hout * p.Wout, p.N, p.Cin, p.KH * p.KW, p.stride, p.ups, p.act == ACT_GEGLU)
+        key = ops.tuning_key(p.B * p.Hout * p.Wout, p.N, p.Cin, p.KH * p.KW, p.stride, p.ups, p.act == ACT_GEGLU, p.Cin2 if p.x2 else 0)
         u = uniq.setdefault(key, {"rec": rec, "count": 0})
         u["count"] += 1
     print(f"{len(log)} launches, {len(uniq)} distinct", flush=True)
     table, rows = {}, []
     for key, u in uniq.items():
         p0 = u["rec"]["params"]
-        M, nK = p0.B * p0.Hout * p0.Wout, p0.KH * p0.KW * (p0.cin_pad // 64)
+        M, nK = p0.B * p0.Hout * p0.Wout, p0.KH * p0.KW * (p0.cin_pad // 64) + ((p0.cin2_pad // 64) if p0.x2 else 0)
         base = clone_params(p0)
         if args.cold:
             xk = u["rec"]["keep"][0]

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-LAUNCHES_PER_STEP = 198
+LAUNCHES_PER_STEP = 184      # aptp_conv_gemm launches of one headline forward (bench.py: roofline.launches_per_step)
 
 
 def family_sum(d, counter):

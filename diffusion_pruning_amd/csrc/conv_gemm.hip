@@ -1217,6 +1217,226 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   run_epilogue<NW, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, wave, ln_mean, ln_rstd, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 / pad-1 convolution with the INPUT HALO KEPT IN LDS (tiles APTP_TILE_HALO_*).
+// The implicit-GEMM kernels above fetch a [BM x 64] activation tile per (tap, channel step): nine shifted copies of almost
+// the same pixels, 16 of the 36 KB a 128x160 tile moves per K-step.  With one workgroup per CU those launches run at the
+// rate their operand bytes in flight allow (Little's law), so fewer bytes per FLOP is the lever.
+// Here the workgroup's 128 output pixels are whole image rows (R = 128 / W of them) and, per 64-channel step, the
+// (R+2) x (W+2) input patch is copied to LDS ONCE (LDS-DMA, zero page outside the image); the nine taps are then nine
+// fragment reads of the same patch at shifted row offsets.  K-loop order is channel-step-major: step kt -> (cc = kt / 9,
+// tap = kt % 9); the weights of one (tap, cc) stream through a STAGES-deep ring exactly as in conv_gemm_dma_kernel, the
+// patch is double-buffered and requested one channel step (nine K-steps) ahead.  Per K-step 20 + 33/9 = 23.7 KB instead of
+// 36 KB.  8 waves (4 x 2), BM = 128, same LDS images (XOR-swizzled 128-byte rows), same epilogues.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BN, int STAGES>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KParams p) {
+  constexpr int BM = 128, WM = 4, WN = 2, NW = 8, NT = 512, RPP = 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MF = WTM / 16, NF = WTN / 16;
+  constexpr int PROWS = 264;                          // (R+2)*(W+2) <= 264 for W = 64 (R = 2), 32 (R = 4), 16 (R = 8)
+  constexpr int P_PASS = (PROWS + RPP - 1) / RPP, B_PASS = (BN + RPP - 1) / RPP;
+  constexpr int D = STAGES - 1;
+  static_assert(WTN % 16 == 0 && STAGES >= 3, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * PROWS * BK + STAGES * BN * BK];
+  __bf16* Ps = smem;
+  __bf16* Bs = smem + 2 * PROWS * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int tm, tn, kz;
+  decode_block(p, tiles_m, tiles_n, tm, tn, kz);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
+  const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+  LnRaw<MF> ln_raw;
+  ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw);
+
+  const int W = p.Wout, PW = W + 2, R = BM / W;
+  const int prows = (R + 2) * PW;
+  const int b_img = m0 / p.HW, oy0 = (m0 - b_img * p.HW) / W;
+
+  // ---- patch source pointers: row prow = (pr, pc) of the patch <-> input pixel (oy0 - 1 + pr, pc - 1) ---------------------
+  const int rowbase = tid >> 3;
+  const int schunk = (tid & 7) ^ ((rowbase >> 1) & 7);      // (rows of one pass differ by 64: same swizzle term)
+  const char* zpage = reinterpret_cast<const char*>(g_zero_page) + schunk * 16;
+  const bool tail_bad = ((p.ncc - 1) * BK + schunk * 8) >= p.Cin;
+  const char* p_ptr[P_PASS];
+#pragma unroll
+  for (int i = 0; i < P_PASS; ++i) {
+    const int pr_ = rowbase + RPP * i;
+    const int pr = pr_ / PW, pc = pr_ - pr * PW;
+    const int iy = oy0 - 1 + pr, ix = pc - 1;
+    const bool ok = pr_ < prows && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+    const unsigned off = ((unsigned)((b_img * p.Hin + iy) * p.Win + ix) * (unsigned)p.ldx) * 2u;   // < 2^31
+    p_ptr[i] = ok ? reinterpret_cast<const char*>(p.x) + off + schunk * 16 : nullptr;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  auto issue_patch = [&](int cc, int pbuf) {
+    const bool bad = tail_bad && cc == p.ncc - 1;
+#pragma unroll
+    for (int i = 0; i < P_PASS; ++i) {
+      if (wave * 8 + RPP * i < prows) {                            // wave-uniform
+        const char* src = (p_ptr[i] && !bad) ? p_ptr[i] + cc * (BK * 2) : zpage;
+        __bf16* dst = Ps + (pbuf * PROWS + wave * 8 + RPP * i) * BK;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+      }
+    }
+  };
+  // ---- weights: step kt -> (cc, tap); packed [N][tap][cin_pad] ---------------------------------------------------------
+  const char* b_row[B_PASS];
+#pragma unroll
+  for (int i = 0; i < B_PASS; ++i) {
+    int n = n0 + rowbase + RPP * i;
+    n = n < p.N ? n : p.N - 1;
+    b_row[i] = reinterpret_cast<const char*>(p.w) + ((int64_t)n * p.Ktot + schunk * 8) * 2;
+  }
+  const int cin_pad = p.ncc * BK;
+  auto issue_w = [&](int kt, int stage) {
+    const int cc = kt / 9, tap = kt - cc * 9;
+    const int koff = (tap * cin_pad + cc * BK) * 2;
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      if (wave * 8 + RPP * i < BN) {
+        __bf16* dst = Bs + (stage * BN + wave * 8 + RPP * i) * BK;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(b_row[i] + koff), (lds_ptr)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  int prow0[MF];                                   // patch row of this lane's output pixel at tap (0, 0)
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int r = wm * WTM + i * 16 + frow;
+    const int lr = r / W;
+    prow0[i] = lr * PW + (r - lr * W);
+  }
+  auto compute = [&](int pbuf, int tap, int stage) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int toff = ky * PW + kx;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 af[MF], wf[NF];
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int pr_ = prow0[i] + toff;
+        const int sw = (s2 * 4 + fq) ^ ((pr_ >> 1) & 7);
+        af[i] = *reinterpret_cast<const bf16x8*>(Ps + (pbuf * PROWS + pr_) * BK + sw * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int r = wn * WTN + j * 16 + frow;
+        const int sw = (s2 * 4 + fq) ^ ((r >> 1) & 7);
+        wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (stage * BN + r) * BK + sw * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  float ln_mean[MF], ln_rstd[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) { ln_mean[i] = 0.f; ln_rstd[i] = 1.f; }
+
+  // ---- main loop: weights ring with D tiles in flight; patch of the next channel step requested at tap 0 --------------------
+  // vmcnt is in order, so the wait that retires weight tile kt+1 must allow exactly the requests issued after it: D-1 weight
+  // tiles plus the patch requests of the last D steps (a plain (D-1)*NLD would retire the newest weight tile too whenever
+  // a patch was just requested: one exposed round trip per channel step).
+  constexpr int B_FULL = BN / RPP;
+  constexpr int NLD_LO = B_FULL, NLD_HI = B_PASS;
+  const bool hi = (NLD_HI != NLD_LO) && (wave * 8 + RPP * (B_PASS - 1) < BN);   // wave-uniform
+  const int nld = hi ? NLD_HI : NLD_LO;
+  int pw_cnt = 0;                                   // patch requests this wave issues per patch (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < P_PASS; ++i) pw_cnt += (wave * 8 + RPP * i < prows) ? 1 : 0;
+  auto wait_vm = [&](int allowed) {                 // s_waitcnt needs an immediate: wave-uniform switch over the few values
+    switch (allowed) {
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  const int n = kt_end - kt_begin;
+  if (n > 0) {
+    const int cc_first = kt_begin / 9;
+    issue_patch(cc_first, cc_first & 1);
+    const int pre = n < D ? n : D;
+    for (int t = 0; t < pre; ++t) issue_w(kt_begin + t, t);
+    ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
+    if (pre == D) {
+      if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int cur = 0, nxt = D % STAGES;
+    int cc = cc_first, tap = kt_begin - cc_first * 9;
+    int since_patch = D;                                // steps since the last patch request (>= D: none in the window)
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool issue = kt + D < kt_end;
+      if (issue) issue_w(kt + D, nxt);
+      // the patch of the next channel step: requested when this step's first tap starts (or at the slice start)
+      if ((tap == 0 || kt == kt_begin) && (cc + 1) * 9 < kt_end) { issue_patch(cc + 1, (cc + 1) & 1); since_patch = 0; }
+      compute(cc & 1, tap, cur);
+      asm volatile("" ::: "memory");
+      if (issue) wait_vm(nld * (D - 1) + (since_patch < D ? pw_cnt : 0));
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ++since_patch;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      cur = cur + 1 == STAGES ? 0 : cur + 1;
+      nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+      if (++tap == 9) { tap = 0; ++cc; }
+    }
+  }
+
+  if (p.split_k > 1 && p.counters) {
+    if (!splitk_combine<NT, MF, NF>(p, acc, tm * tiles_n + tn, kz, tid, reinterpret_cast<int*>(smem))) return;
+    ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw, true);
+    ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd, true);
+  } else
+  if (p.split_k > 1) {
+    float* ws = p.ws + (int64_t)kz * p.M * p.ws_ld;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int nn = n0 + wn * WTN + j * 16 + fq * 4;
+        if (nn >= p.N) continue;
+        float4 o; o.x = acc[i][j][0]; o.y = acc[i][j][1]; o.z = acc[i][j][2]; o.w = acc[i][j][3];
+        *reinterpret_cast<float4*>(ws + (int64_t)m * p.ws_ld + nn) = o;
+      }
+    }
+    return;
+  }
+  static_assert(NW * 16 * (WTN + 4) * 4 <= (int)sizeof(smem), "epilogue transpose buffer");
+  run_epilogue<NW, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, wave, ln_mean, ln_rstd, smem);
+}
+
 // split-K reducer + epilogue: one thread per (row, 4 packed columns)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
   const int quads = (p.act == APTP_ACT_GEGLU) ? p.N / 8 : p.N / 4;   // GEGLU: one thread per h-quad (+ its g-quad)
@@ -1268,8 +1488,10 @@ const TileCfg kTiles[] = {
     {64, 128, 2, 4}, {64, 64, 2, 4}, {128, 64, 2, 4}, {128, 128, 2, 4}, {128, 160, 2, 8}, {128, 160, 2, 8},
     {128, 128, 4, 8}, {128, 128, 4, 8}, {256, 128, 2, 8}, {128, 160, 2, 8}, {128, 160, 2, 8}, {128, 128, 4, 8},
     {128, 128, 4, 8}, {64, 160, 2, 8}, {64, 128, 4, 8}, {64, 160, 2, 8}, {128, 64, 2, 8}, {256, 128, 2, 8},
-    {128, 256, 4, 8}};
-constexpr int kNumTiles = 43;
+    {128, 256, 4, 8},
+    {128, 160, 2, 8}, {128, 128, 2, 8}};      // 43, 44: 3x3 halo-in-LDS kernel (conv3x3_halo_kernel)
+constexpr int kNumTiles = 45;
+static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == kNumTiles, "tile table");
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
   if (p->tile != APTP_TILE_AUTO) return p->tile;
@@ -1535,6 +1757,20 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_PP4_128x64: launch_tile_pp<128, 64, 4, 2, 4>(k, s); break;
     case APTP_TILE_PP3_256x128: launch_tile_pp<256, 128, 4, 2, 3>(k, s); break;
     case APTP_TILE_PP3_128x256: launch_tile_pp<128, 256, 2, 4, 3>(k, s); break;
+    case APTP_TILE_HALO_128x160:
+    case APTP_TILE_HALO_128x128: {
+      // whole image rows per tile, the patch (R+2) x (W+2) must fit the 264-row LDS image, no second operand
+      const int W = p->Wout;
+      if (!(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->ups == 0 && !p->x2 && W > 0 && 128 % W == 0 &&
+            (p->Hout * W) % 128 == 0 && (128 / W + 2) * (W + 2) <= 264)) {
+        aptp_set_error("conv_gemm: the halo tiles need a 3x3 / stride-1 / pad-1 convolution without x2 whose width divides 128 (16, 32 or 64)");
+        return APTP_EINVAL;
+      }
+      const int tiles = ((k.M + 127) / 128) * ((k.N + kTiles[t].bn - 1) / kTiles[t].bn);
+      if (t == APTP_TILE_HALO_128x160) hipLaunchKernelGGL((conv3x3_halo_kernel<160, 4>), dim3(tiles * k.split_k), dim3(512), 0, s, k);
+      else hipLaunchKernelGGL((conv3x3_halo_kernel<128, 4>), dim3(tiles * k.split_k), dim3(512), 0, s, k);
+      break;
+    }
     default: aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL;
   }
   APTP_LAUNCH_CHECK();

@@ -143,7 +143,10 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        /* LDS-DMA, 8 waves in two groups that alternate load and MFMA slots (ping-pong), 3- or 4-stage ring */
        APTP_TILE_PP3_128x160 = 33, APTP_TILE_PP4_128x160 = 34, APTP_TILE_PP3_128x128 = 35, APTP_TILE_PP4_128x128 = 36,
        APTP_TILE_PP4_64x160 = 37, APTP_TILE_PP4_64x128 = 38, APTP_TILE_PP5_64x160 = 39, APTP_TILE_PP4_128x64 = 40,
-       APTP_TILE_PP3_256x128 = 41, APTP_TILE_PP3_128x256 = 42 };
+       APTP_TILE_PP3_256x128 = 41, APTP_TILE_PP3_128x256 = 42,
+       /* 3x3 / stride-1 / pad-1 only, image width 16 / 32 / 64: the input halo of 128 output pixels (whole image rows) is
+        * kept in LDS across the nine taps, weights stream through a 4-stage ring (8 waves) */
+       APTP_TILE_HALO_128x160 = 43, APTP_TILE_HALO_128x128 = 44 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

@@ -93,6 +93,15 @@ CONV_CASES = [
     (1, 8, 8, 1280, 1280, 3, 1, 0, 9, 4),
     (2, 16, 16, 192, 128, 1, 1, 0, 7, 1),
     (4, 64, 64, 320, 320, 3, 1, 0, 10, 1),     # full level-64 shape
+    # 3x3 halo-in-LDS kernel (tiles 43, 44): image widths 64 / 32 / 16, ragged N and Cin, split-K slices that start mid channel step
+    (2, 64, 64, 64, 160, 3, 1, 0, 43, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 43, 1),
+    (4, 64, 64, 320, 160, 3, 1, 0, 43, 2),
+    (2, 32, 32, 160, 320, 3, 1, 0, 43, 1),
+    (2, 32, 32, 320, 136, 3, 1, 0, 44, 3),
+    (4, 16, 16, 72, 200, 3, 1, 0, 43, 1),
+    (1, 64, 64, 640, 128, 3, 1, 0, 44, 4),
+    (3, 32, 32, 1280, 320, 3, 1, 0, 43, 7),
     # 3-stage LDS-DMA ring (tiles 13..18): counted vmcnt + raw barrier; short and long K, split-K slices of 1-2 steps
     (2, 16, 16, 64, 64, 3, 1, 0, 13, 1),
     (2, 32, 32, 160, 320, 3, 1, 0, 14, 1),

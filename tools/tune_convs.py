@@ -124,7 +124,7 @@ def main():
         else:
             timer = lambda q: time_launch(lib, q)
         t_base = timer(base)
-        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18, 21, 22, 24, 25, 26, 27, 30, 31, 32, 35, 36, 38, 40] if p0.act == ACT_GEGLU else list(range(1, 41))
+        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18, 21, 22, 24, 25, 26, 27, 30, 31, 32, 35, 36, 38, 40] if p0.act == ACT_GEGLU else list(range(1, 45))
         splits = [1, 2, 3, 4, 6, 8, 12, 16, 24]
         if args.quick:
             splits = [1, 2, 4, 8]

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusion_pruning_amd import ops
 dev = torch.device("cuda:0")

@@ -242,39 +242,40 @@ __device__ __forceinline__ void ln_finish(const KParams& p, float a, float a2, R
 // With rstat_out, each wave also emits its rows' (sum, sumsq) over the columns it owns into slot tn*WN + wn: the four
 // lanes that share a row (lane>>4 = 0..3) fold their partial sums with two cross-lane adds.
 // Folded LayerNorm: mean / rstd of this lane's MF rows from the producer's partials [slots][M] (sum, sumsq).
-// Two halves, both in the kernel PROLOGUE: ln_rows_issue() at the very top requests the first 16 slots (the four lanes that
-// share a row split the slots, slot = fq, fq+4, ...; all MF rows per lane => 4*MF independent 8-byte loads), and
+// Two halves, both in the kernel PROLOGUE: ln_rows_issue() at the very top requests the first 32 slots (the four lanes that
+// share a row split the slot PAIRS, pair = fq, fq+4, ...; all MF rows per lane => up to 4*MF independent 16-byte loads), and
 // ln_rows_finish(), called after the first operand tiles have been requested, folds them.  Its wait coincides with the
 // wait for operand tile 0, so the statistics cost no extra memory round trip (in the epilogue, or requested after the
 // operand tiles, they cost every workgroup one loaded L2 round trip: +3..6 us per launch on the GEGLU projections).
-// More than 16 slots (a 1280-wide producer on 64-wide tiles) take further rounds inside ln_rows_finish.  Fixed fold
+// More than 32 slots (a 1280-wide producer on 64-wide tiles) take further rounds inside ln_rows_finish.  Fixed fold
 // order: deterministic.
 template <int MF>
-struct LnRaw { float2 v[4][MF]; int mr[MF]; };
+struct LnRaw { float4 v[4][MF]; int mr[MF]; };
 
 template <int MF, int WTM>
 __device__ __forceinline__ void ln_rows_issue(const KParams& p, int m0, int wm, int lane, LnRaw<MF>& raw, bool split_ok = false) {
   // (split-K: only the workgroup that combines the slices needs the rows, and asks for them then)
   if (!p.ln_stats || (p.split_k > 1 && !split_ok) || (APTP_ABLATE & 128)) return;
   const int frow = lane & 15, fq = lane >> 4;
-  const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
+  const float4* sp = reinterpret_cast<const float4*>(p.ln_stats);     // [slots/2][M]: two slots per 16-byte element
+  const int npair = p.ln_slots >> 1;
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const int m = m0 + wm * WTM + i * 16 + frow;
     raw.mr[i] = m < p.M ? m : p.M - 1;
   }
   // (these short-K launches are bound by the vector-memory instruction rate, so rounds with no live slot are skipped
-  // by a wave-uniform branch: MF * ceil(slots/4) load instructions per wave, every lane a distinct (row, slot))
+  // by a wave-uniform branch: MF * ceil(slots/8) load instructions per wave, every lane a distinct (row, slot pair))
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    if (u * 4 < p.ln_slots) {
-      const int sl = u * 4 + fq;
-      const int64_t row0 = (int64_t)(sl < p.ln_slots ? sl : 0) * p.M;
+    if (u * 4 < npair) {
+      const int pr = u * 4 + fq;
+      const int64_t row0 = (int64_t)(pr < npair ? pr : 0) * p.M;
 #pragma unroll
       for (int i = 0; i < MF; ++i) raw.v[u][i] = sp[row0 + raw.mr[i]];
     } else {
 #pragma unroll
-      for (int i = 0; i < MF; ++i) raw.v[u][i] = make_float2(0.f, 0.f);
+      for (int i = 0; i < MF; ++i) raw.v[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   asm volatile("" ::: "memory");      // keep the requests here, ahead of the address generation and the operand DMA
@@ -285,27 +286,31 @@ __device__ __forceinline__ void ln_rows_finish(const KParams& p, int lane, const
                                                bool split_ok = false) {
   if (!p.ln_stats || (p.split_k > 1 && !split_ok) || (APTP_ABLATE & 128)) return;
   const int fq = lane >> 4;
-  const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
+  const float4* sp = reinterpret_cast<const float4*>(p.ln_stats);
+  const int npair = p.ln_slots >> 1;
   float lna[MF], lna2[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) { lna[i] = 0.f; lna2[i] = 0.f; }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const bool ok = u * 4 + fq < p.ln_slots;
+    const bool ok = u * 4 + fq < npair;
 #pragma unroll
-    for (int i = 0; i < MF; ++i) { lna[i] += ok ? raw.v[u][i].x : 0.f; lna2[i] += ok ? raw.v[u][i].y : 0.f; }
+    for (int i = 0; i < MF; ++i) {
+      lna[i] += ok ? raw.v[u][i].x + raw.v[u][i].z : 0.f;
+      lna2[i] += ok ? raw.v[u][i].y + raw.v[u][i].w : 0.f;
+    }
   }
-  for (int base = 16; base < p.ln_slots; base += 16) {
+  for (int base = 16; base < npair; base += 16) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (base + u * 4 < p.ln_slots) {
-        const int sl = base + u * 4 + fq;
-        const bool ok = sl < p.ln_slots;
-        const int64_t row0 = (int64_t)(ok ? sl : 0) * p.M;
+      if (base + u * 4 < npair) {
+        const int pr = base + u * 4 + fq;
+        const bool ok = pr < npair;
+        const int64_t row0 = (int64_t)(ok ? pr : 0) * p.M;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-          const float2 t = sp[row0 + raw.mr[i]];
-          lna[i] += ok ? t.x : 0.f; lna2[i] += ok ? t.y : 0.f;
+          const float4 t = sp[row0 + raw.mr[i]];
+          lna[i] += ok ? t.x + t.z : 0.f; lna2[i] += ok ? t.y + t.w : 0.f;
         }
       }
     }
@@ -358,7 +363,8 @@ __device__ __forceinline__ void tile_epilogue(const KParams& p, f32x4 (&acc)[MF]
       st[0] += __shfl_xor(st[0], 32); st[1] += __shfl_xor(st[1], 32);
       if (fq == 0) {
         float2 o; o.x = st[0]; o.y = st[1];
-        reinterpret_cast<float2*>(p.rstat_out)[(int64_t)(tn * WN + wn) * p.M + m] = o;   // [slots][M]: 16 rows = 128 B
+        const int slot = tn * WN + wn;     // [slots/2][M][2 slots x (sum, sumsq)]: the consumer reads two slots per 16-byte load
+        reinterpret_cast<float2*>(p.rstat_out)[((int64_t)(slot >> 1) * p.M + m) * 2 + (slot & 1)] = o;
       }
     }
   }
@@ -498,7 +504,8 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
           for (int off = 1; off < LPR; off <<= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
           if (lrow < RPP && r < 16 && m2 < p.M && lc8 == 0) {   // (also for a wave past the last column: its slot reads 0)
             float2 q; q.x = s0; q.y = s1;
-            reinterpret_cast<float2*>(p.rstat_out)[(int64_t)(tn * WN + wn) * p.M + m2] = q;
+            const int slot = tn * WN + wn;
+            reinterpret_cast<float2*>(p.rstat_out)[((int64_t)(slot >> 1) * p.M + m2) * 2 + (slot & 1)] = q;
           }
         }
       }
@@ -1469,9 +1476,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
   RowCtx rc;
   row_info(p, m, rc);
   if (p.ln_stats) {
-    const float2* sp = reinterpret_cast<const float2*>(p.ln_stats);
+    const float4* sp = reinterpret_cast<const float4*>(p.ln_stats);
     float a = 0.f, a2 = 0.f;
-    for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 t = sp[(int64_t)sl * p.M + m]; a += t.x; a2 += t.y; }
+    for (int pr = 0; pr < (p.ln_slots >> 1); ++pr) { const float4 t = sp[(int64_t)pr * p.M + m]; a += t.x + t.z; a2 += t.y + t.w; }
     ln_finish(p, a, a2, rc);
   }
   float st[2] = {0.f, 0.f};     // (row statistics are only emitted by the un-split kernel: checked on the host)
@@ -1573,10 +1580,10 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   k.rstat_out = p->rowstat_out; k.rstat_slots = p->rowstat_slots;
   k.ln_stats = p->ln_stats; k.ln_slots = p->ln_slots; k.ln_colsum = p->ln_colsum; k.ln_eps = p->ln_eps;
   k.ln_invC = p->ln_C > 0 ? 1.0f / (float)p->ln_C : 0.f;
-  APTP_CHECK(!p->rowstat_out || (!geglu && !p->out_f32 && ((uintptr_t)p->rowstat_out % 8) == 0),
+  APTP_CHECK(!p->rowstat_out || (!geglu && !p->out_f32 && ((uintptr_t)p->rowstat_out % 16) == 0),
              "conv_gemm: rowstat_out needs a bf16, non-GEGLU output and an 8-byte aligned buffer");
   APTP_CHECK(!p->ln_stats || (p->ln_colsum && p->ln_slots > 0 && p->ln_C > 0 && p->KH == 1 && p->KW == 1 &&
-                              ((uintptr_t)p->ln_stats % 8) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
+                              p->ln_slots % 2 == 0 && ((uintptr_t)p->ln_stats % 16) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
              "conv_gemm: folded LayerNorm needs ln_colsum [N], ln_slots > 0, ln_C > 0 and a 1x1 filter");
   k.counters = p->tile_counters;
   k.cstat_out = p->colstat_out; k.cstat_ld = p->colstat_ld;

@@ -309,7 +309,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               rowstats: bool = False, ln=None, colstats: bool = False, x2: Optional[torch.Tensor] = None):
     """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites.
     rowstats: also emit the per-row (sum, sumsq) partials of y a following folded LayerNorm needs; returns (y, stats)
-    with stats fp32 [slots, M, 2], or (y, None) when this launch is split along K (the caller then normalises with
+    with stats fp32 [slots / 2, M, 4] (two (sum, sumsq) slots per element), or (y, None) when this launch is split along K (the caller then normalises with
     ops.layernorm).  ln = (stats, eps): x is the un-normalised input of a LayerNorm folded into pw (pack_weight ln_gamma)."""
     lib = _lib.load()
     _check_act(x, "conv_gemm x")
@@ -406,7 +406,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     stats = None
     if rowstats and (p.split_k == 1 or cnt is not None):
         slots = lib.aptp_conv_gemm_rowstat_slots(ctypes.byref(p))
-        stats = torch.empty(slots, B * Hout * Wout, 2, dtype=torch.float32, device=x.device)
+        assert slots % 2 == 0
+        stats = torch.empty(slots // 2, B * Hout * Wout, 4, dtype=torch.float32, device=x.device)
         p.rowstat_out, p.rowstat_slots = stats.data_ptr(), slots
     cstats = None
     if colstats and COLSTATS and Hout * Wout >= COLSTATS_MIN_HW and act != ACT_GEGLU and not out_f32 \
@@ -424,8 +425,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         if pw.ln_colsum is None:
             raise ValueError("conv_gemm: ln= needs weights packed with ln_gamma / ln_beta")
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.shape[1] == B * Hout * Wout \
-            and ln_stats.shape[2] == 2
-        p.ln_stats, p.ln_slots, p.ln_colsum = ln_stats.data_ptr(), ln_stats.shape[0], pw.ln_colsum.data_ptr()
+            and ln_stats.shape[2] == 4
+        p.ln_stats, p.ln_slots, p.ln_colsum = ln_stats.data_ptr(), 2 * ln_stats.shape[0], pw.ln_colsum.data_ptr()
         p.ln_eps, p.ln_C = ln_eps, Cx
     elif pw.ln_colsum is not None:
         raise ValueError("conv_gemm: weights with a folded LayerNorm need ln=(stats, eps)")

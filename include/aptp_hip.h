@@ -88,10 +88,11 @@ typedef struct {
   /* LayerNorm folded into the neighbouring GEMMs (nn.LayerNorm norm1/norm2/norm3 of BasicTransformerBlock,
    * blocks.py:782,808-810,821; inference path).  The GEMM that PRODUCES the normalised tensor (proj_in, to_out with its
    * residual) also emits, per output row, fp32 (sum, sumsq) partials of the bf16 values it stores, one per (N-tile, wave
-   * column): rowstat_out [rowstat_slots, M, 2], rowstat_slots = aptp_conv_gemm_rowstat_slots(); needs split_k == 1, a bf16
+   * column): rowstat_out [rowstat_slots / 2, M, 2, 2] (two slots per 16-byte element; the slot count is always even),
+   * rowstat_slots = aptp_conv_gemm_rowstat_slots(); needs split_k == 1 or tile_counters, a bf16
    * non-GEGLU output.  The GEMM that CONSUMES LayerNorm(x) reads x itself with gamma folded into its packed weights
    * (w' = w * gamma) and finishes the normalisation in its epilogue, before bias:
-   *     v = rstd[m] * (acc[m, n] - mean[m] * ln_colsum[n]),   mean/rstd from ln_stats [ln_slots, M, 2] over ln_C channels,
+   *     v = rstd[m] * (acc[m, n] - mean[m] * ln_colsum[n]),   mean/rstd from ln_stats [ln_slots / 2, M, 2, 2] over ln_C channels,
    * ln_colsum[n] = sum_k bf16(w'[n, k]) (fp32), and the caller adds sum_k beta[k] w[n, k] to bias[n]. */
   float* rowstat_out;
   int32_t rowstat_slots;

@@ -38,9 +38,9 @@ def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colga
     if ln is not None:          # LayerNorm folded into the packed weights (include/aptp_hip.h, ln_stats)
         stats, eps = ln
         assert pw.ln_colsum is not None and pw.KH == 1
-        tot = stats.sum(0)
-        mean = tot[:, 0] / C
-        rstd = torch.rsqrt((tot[:, 1] / C - mean * mean).clamp_min(0) + eps)
+        tot = stats.sum(0)                         # [M, 4]: two (sum, sumsq) slots per element
+        mean = (tot[:, 0] + tot[:, 2]) / C
+        rstd = torch.rsqrt(((tot[:, 1] + tot[:, 3]) / C - mean * mean).clamp_min(0) + eps)
         mean, rstd = (t.reshape(B, 1, y.shape[2], y.shape[3]) for t in (mean, rstd))
         y = rstd * (y - mean * pw.ln_colsum[None, :, None, None])
     else:
@@ -79,7 +79,8 @@ def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colga
     stats = None
     if rowstats:
         yf = y.float().reshape(-1, y.shape[-1])
-        stats = torch.stack([yf.sum(1), (yf * yf).sum(1)], 1).reshape(1, -1, 2).contiguous()
+        zz = torch.zeros_like(yf[:, 0])
+        stats = torch.stack([yf.sum(1), (yf * yf).sum(1), zz, zz], 1).reshape(1, -1, 4).contiguous()
     if out is not None:
         out.copy_(y)
         y = out

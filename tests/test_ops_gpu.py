@@ -552,17 +552,18 @@ def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile, both_epilogues
     y, st = ops.linear(x.to(cuda), pw, residual=res.to(cuda), rowstats=True, tile=tile, split_k=1)
     ref = F.linear(x.float(), w.float(), b) + res.float()
     assert rel_l2(y.float().cpu(), ref) <= REL_L2_TOL
-    assert st.shape[1] == rows and st.shape[2] == 2
+    assert st.shape[1] == rows and st.shape[2] == 4            # two (sum, sumsq) slots per 16-byte element
     tot = st.sum(0).cpu().double()
     yf = y[0].double().cpu()
-    assert torch.allclose(tot[:, 0], yf.sum(1), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(tot[:, 1], (yf * yf).sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(tot[:, 0] + tot[:, 2], yf.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(tot[:, 1] + tot[:, 3], (yf * yf).sum(1), rtol=1e-5, atol=1e-3)
     # split along K: the workgroup that combines the slices emits the statistics (in-kernel reduction) ...
     y2, st2 = ops.linear(x.to(cuda), pw, residual=res.to(cuda), rowstats=True, tile=tile, split_k=2)
     assert rel_l2(y2.float().cpu(), ref) <= REL_L2_TOL
     if C >= 128:      # (a single K-step cannot be split)
         y2f = y2[0].double().cpu()
-        assert torch.allclose(st2.sum(0).cpu().double()[:, 0], y2f.sum(1), rtol=1e-5, atol=1e-3)
+        t2 = st2.sum(0).cpu().double()
+        assert torch.allclose(t2[:, 0] + t2[:, 2], y2f.sum(1), rtol=1e-5, atol=1e-3)
     # ... and with the separate reduce launch there are none: the caller falls back to the LayerNorm kernel
     ops.SPLITK_IN_KERNEL = False
     try:

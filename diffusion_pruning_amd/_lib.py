@@ -194,6 +194,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles the HIP runtime (torch/lib/libamdhip64.so), and the process must end up with ONE
+    # runtime.  Loaded after torch, libaptp_hip.so's libamdhip64.so.7 dependency resolves to the copy torch already
+    # mapped; loaded before it, /opt/rocm's copy comes in as a second runtime and every launch on a torch stream fails with
+    # "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AptpError(
             f"{LIB_PATH} not found: the HIP extension is the only compute path of diffusion_pruning_amd. "

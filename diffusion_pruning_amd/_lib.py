@@ -122,6 +122,21 @@ class GroupNormBwdParams(Structure):
     ]
 
 
+class UnetPrologueParams(Structure):
+    _fields_ = [
+        ("sample", c_void_p), ("sample_bf16", c_int32), ("x", c_void_p),
+        ("B", c_int32), ("C", c_int32), ("H", c_int32), ("W", c_int32), ("cin_pad", c_int32),
+        ("timesteps", c_void_p), ("freqs", c_void_p), ("half", c_int32), ("t_emb", c_void_p),
+    ]
+
+
+class UnetEpilogueParams(Structure):
+    _fields_ = [
+        ("y", c_void_p), ("ldy", c_int64), ("out", c_void_p), ("out_bf16", c_int32),
+        ("B", c_int32), ("C", c_int32), ("H", c_int32), ("W", c_int32),
+    ]
+
+
 class ColsumParams(Structure):
     _fields_ = [("x", c_void_p), ("ldx", c_int64), ("rows", c_int32), ("C", c_int32), ("partial", c_void_p)]
 
@@ -178,6 +193,8 @@ EXPORTS = [
     ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),
     ("aptp_colsum", c_int, [POINTER(ColsumParams), c_void_p]),
     ("aptp_layernorm_pgrad", c_int, [POINTER(LayerNormPgradParams), c_void_p]),
+    ("aptp_unet_prologue", c_int, [POINTER(UnetPrologueParams), c_void_p]),
+    ("aptp_unet_epilogue", c_int, [POINTER(UnetEpilogueParams), c_void_p]),
     ("aptp_last_error", c_char_p, []),
     ("aptp_version", c_int, []),
 ]

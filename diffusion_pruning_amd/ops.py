@@ -14,6 +14,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from ._lib import UnetEpilogueParams, UnetPrologueParams
 from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, GateBwdParams,
                    GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
                    ColsumParams, LayerNormPgradParams)
@@ -535,6 +536,38 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (B, heads, Lq)
         p.lse = lse.data_ptr()
     _lib.check(lib.aptp_attention(ctypes.byref(p), _stream()), "aptp_attention")
+    return out
+
+
+def unet_prologue(sample: torch.Tensor, timesteps: torch.Tensor, freqs: torch.Tensor, cin_pad: int):
+    """sample [B,C,H,W] (fp32 / bf16, NCHW contiguous) -> (x bf16 [B,H,W,cin_pad] with zero padding channels,
+    t_emb bf16 [B, 2*len(freqs)] = [cos | sin] of timesteps * freqs) in one launch (include/aptp_hip.h)."""
+    lib = _lib.load()
+    assert sample.is_cuda and sample.dim() == 4 and sample.dtype in (torch.float32, torch.bfloat16)
+    sample = sample.contiguous()
+    B, C, H, W = sample.shape
+    t = timesteps.to(device=sample.device, dtype=torch.float32).contiguous()
+    assert t.numel() == B and freqs.dtype == torch.float32 and freqs.is_contiguous()
+    x = torch.empty(B, H, W, cin_pad, dtype=torch.bfloat16, device=sample.device)
+    temb = torch.empty(B, 2 * freqs.numel(), dtype=torch.bfloat16, device=sample.device)
+    p = UnetPrologueParams()
+    p.sample, p.sample_bf16, p.x = sample.data_ptr(), int(sample.dtype == torch.bfloat16), x.data_ptr()
+    p.B, p.C, p.H, p.W, p.cin_pad = B, C, H, W, cin_pad
+    p.timesteps, p.freqs, p.half, p.t_emb = t.data_ptr(), freqs.data_ptr(), freqs.numel(), temb.data_ptr()
+    _lib.check(lib.aptp_unet_prologue(ctypes.byref(p), _stream()), "aptp_unet_prologue")
+    return x, temb
+
+
+def unet_epilogue(y: torch.Tensor, channels: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """conv_out's fp32 [B,H,W,ld] -> [B,channels,H,W] (fp32 or bf16) in one launch."""
+    lib = _lib.load()
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and out_dtype in (torch.float32, torch.bfloat16)
+    B, H, W, ld = y.shape
+    out = torch.empty(B, channels, H, W, dtype=out_dtype, device=y.device)
+    p = UnetEpilogueParams()
+    p.y, p.ldy, p.out, p.out_bf16 = y.data_ptr(), ld, out.data_ptr(), int(out_dtype == torch.bfloat16)
+    p.B, p.C, p.H, p.W = B, channels, H, W
+    _lib.check(lib.aptp_unet_epilogue(ctypes.byref(p), _stream()), "aptp_unet_epilogue")
     return out
 
 

@@ -1559,8 +1559,14 @@ class UNet2DConditionModelGated(nn.Module):
         elif timesteps.dim() == 0:
             timesteps = timesteps[None].to(dev)
         timesteps = timesteps.to(dev).expand(B)
-        ang = timesteps.float()[:, None] * misc["freqs"][None, :]
-        t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
+        fused_io = sample.is_cuda and sample.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled()
+        if fused_io:
+            # one launch: sinusoid [cos|sin] as bf16 + the channel-padded channels-last copy of the sample
+            x, t_emb = ops.unet_prologue(sample, timesteps, misc["freqs"], misc["cin_pad"])
+        else:
+            ang = timesteps.float()[:, None] * misc["freqs"][None, :]
+            t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
+            x = None
         e1 = ops.linear(t_emb[None], misc["t1"], act=ops.ACT_SILU)
         emb_silu = ops.linear(e1, misc["t2"], act=ops.ACT_SILU)           # bf16 [1, B, T] = SiLU(emb)
         tproj = ops.linear(emb_silu, bp["temb_pw"], out_f32=True)[0]      # fp32 [B, sum Npad]
@@ -1578,8 +1584,9 @@ class UNet2DConditionModelGated(nn.Module):
             ctx = self._project_context(ehs_in, bp, dev)
 
         # 2. pre-process: conv_in on the channel-padded NHWC input
-        x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
-        x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
+        if x is None:
+            x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
+            x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
         conv_in_dst = self._register_cat_slots(B, x.shape[1], x.shape[2], misc["conv_in"].N, dev)
         h = _nchw(ops.conv_gemm(x, misc["conv_in"], out=conv_in_dst, colstats=True))
 
@@ -1609,6 +1616,9 @@ class UNet2DConditionModelGated(nn.Module):
         else:
             a = ops.groupnorm(_nhwc(h), misc["gn_g"], misc["gn_b"], self.conv_norm_out.num_groups, self.conv_norm_out.eps, True)
             y = ops.conv_gemm(a, misc["conv_out"], out_f32=True)            # fp32 [B,H,W,roundup8(out)]
+            if fused_io:
+                out = ops.unet_epilogue(y, self.out_channels, out_dtype)
+                return (out,) if not return_dict else UNet2DConditionOutput(sample=out)
         out = y[..., :self.out_channels].permute(0, 3, 1, 2).to(out_dtype)
         if not return_dict:
             return (out,)

@@ -240,6 +240,33 @@ typedef struct {
 
 int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream);
 
+/*
+ * The two non-GEMM ends of UNet2DConditionModel.forward (unet_2d_conditional.py:1497-1519 time embedding input,
+ * :1614 conv_in input layout, :1721-1726 output): one launch each instead of ~10 elementwise kernels.
+ *   prologue: sample [B, C, H, W] (fp32, or bf16 when sample_bf16) -> x bf16 [B, H, W, cin_pad] (padding channels zero);
+ *             t_emb[b] = [cos(timesteps[b] * freqs[k]) | sin(timesteps[b] * freqs[k])], k < half, as bf16 [B, 2*half]
+ *             (diffusers get_timestep_embedding with flip_sin_to_cos = True).
+ *   epilogue: y fp32 [B, H, W, ldy] (conv_out) -> out [B, C, H, W] (fp32, or bf16 when out_bf16).
+ */
+typedef struct {
+  const void* sample; int32_t sample_bf16;
+  void* x;
+  int32_t B, C, H, W, cin_pad;
+  const float* timesteps;   /* fp32 [B] */
+  const float* freqs;       /* fp32 [half] */
+  int32_t half;
+  void* t_emb;              /* bf16 [B, 2*half] */
+} AptpUnetPrologueParams;
+
+typedef struct {
+  const float* y; int64_t ldy;
+  void* out; int32_t out_bf16;
+  int32_t B, C, H, W;
+} AptpUnetEpilogueParams;
+
+int aptp_unet_prologue(const AptpUnetPrologueParams* p, aptp_stream_t stream);
+int aptp_unet_epilogue(const AptpUnetEpilogueParams* p, aptp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Backward path (data gradients + gate gradients; the U-Net weights are frozen in APTP's pruning step,
  * pdm/training/trainer.py:742,827-829).  Data gradients of convolutions / linears reuse aptp_conv_gemm with

@@ -655,6 +655,26 @@ def test_attention_fused_qkv_views_and_spike(ops, cuda, both_attn_forms):
     assert rel_l2(o.float().cpu(), ref) <= 6e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_prologue_and_epilogue(ops, cuda, dtype):
+    """the non-GEMM ends of UNet2DConditionModel.forward (unet_2d_conditional.py:1497-1519,1614,1721-1726): channel-padded
+    channels-last staging of the sample + the [cos|sin] timestep embedding, and the NCHW output in the caller's dtype"""
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W, half = 3, 4, 24, 40, 160
+    sample = _rand((B, C, H, W), g).to(dtype)
+    t = torch.tensor([0, 500, 999])
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    x, temb = ops.unet_prologue(sample.to(cuda), t.to(cuda), freqs.to(cuda), 8)
+    assert x.shape == (B, H, W, 8) and float(x[..., C:].abs().max()) == 0.0
+    assert torch.equal(x[..., :C].cpu(), sample.permute(0, 2, 3, 1).to(torch.bfloat16))
+    ang = t.float()[:, None] * freqs[None, :]
+    ref = torch.cat([torch.cos(ang), torch.sin(ang)], -1)
+    assert float((temb.float().cpu() - ref).abs().max()) <= 2 ** -8 + 2e-4      # bf16 rounding + sin/cos at |x| <= 1000
+    y = _rand((B, H, W, 8), g).to(cuda)
+    out = ops.unet_epilogue(y, C, dtype)
+    assert out.dtype == dtype and torch.equal(out.cpu(), y[..., :C].permute(0, 3, 1, 2).to(dtype).cpu())
+
+
 def test_bad_arguments_fail_loudly(ops, cuda):
     from diffusion_pruning_amd._lib import AptpError
     x = torch.zeros(1, 4, 4, 12, dtype=torch.bfloat16, device=cuda)   # Cin not a multiple of 8

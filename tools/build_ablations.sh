@@ -11,6 +11,6 @@ for n in "$@"; do
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$CS -Wno-unused-function -DAPTP_ABLATE=$n \
     -c $CS/conv_gemm.hip -o $ROOT/tools/_abl/conv_gemm_$n.o && \
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/tools/_abl/libaptp_abl$n.so $ROOT/tools/_abl/conv_gemm_$n.o \
-    $CS/norm.o $CS/attention.o $CS/attention_bwd.o $CS/train_ops.o $CS/abi.o ) &
+    $CS/norm.o $CS/attention.o $CS/attention_bwd.o $CS/train_ops.o $CS/unet_io.o $CS/abi.o ) &
 done
 wait

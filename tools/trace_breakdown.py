@@ -28,8 +28,8 @@ def main(path, skip_tail=0):
             best = p
             break
     # bench.py ends with other work (roofline leg, copies): if the tail is not the forward graph, locate the replays by a
-    # kernel that runs once per forward (the timestep sinusoid) and take the last three equal-length periods
-    marks = [i for i, nm in enumerate(names) if "sin_kernel" in nm]
+    # kernel that runs once per forward (the U-Net prologue / timestep sinusoid) and take the last three equal-length periods
+    marks = [i for i, nm in enumerate(names) if "unet_prologue_kernel" in nm or "sin_kernel" in nm]
     if len(marks) >= 4 and (best is None or best < 100):
         for j in range(len(marks) - 1, 2, -1):
             p = marks[j] - marks[j - 1]

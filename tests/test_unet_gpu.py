@@ -62,6 +62,24 @@ def test_fixed_half_mask_gated_semantics(tiny, cuda):
     assert ep > 2 * e, (e, ep)   # the beta term is really there: we match gated, not pruned, semantics
 
 
+@pytest.mark.parametrize("batch,latent,masked", [(3, 40, True), (1, 48, False), (2, 32, True), (1, 64, True)])
+def test_other_resolutions_and_batches(tiny, cuda, batch, latent, masked):
+    """latent sizes whose first levels are large maps (HW >= 1024: producer-emitted GroupNorm statistics, in-place
+    skip-concats) with widths that are not powers of two (40, 48: statistics row blocks / tiles straddle image rows and
+    samples), odd batch sizes, gated and dense: SURVEY 8d 'other resolutions'"""
+    from diffusion_pruning_amd import unet as U
+    cfg, model, params = tiny
+    sample, t, ehs = O.synthetic_inputs(cfg, batch, latent)
+    mask = O.fixed_half_mask(cfg) if masked else O.ones_mask(cfg)
+    ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
+    U.CAT_STATS.update(views=0, copies=0)
+    out = run(model, cuda, mask, sample, t, ehs)
+    assert out.shape == ref.shape
+    e = rel_l2(out, ref)
+    assert e <= TOL, e
+    assert U.CAT_STATS["copies"] == 0 and U.CAT_STATS["views"] == sum(len(b.resnets) for b in model.up_blocks)
+
+
 @pytest.mark.parametrize("seed,keep,ndoff", [(1, 0.4, 2), (2, 0.75, 4), (3, 0.55, 0)])
 def test_random_hard_masks_with_depth(tiny, cuda, seed, keep, ndoff):
     cfg, model, params = tiny

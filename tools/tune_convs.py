@@ -84,11 +84,16 @@ def main():
     ap.add_argument("--orders", action="store_true", help="also tune the XCD-aware workgroup order (include/aptp_hip.h)")
     ap.add_argument("--modes", action="store_true", help="also tune the split-K form: in-kernel reduction vs reduce launch")
     ap.add_argument("--refine", action="store_true", help="start from the committed table: a candidate must beat the current entry by 3 %")
+    ap.add_argument("--train", action="store_true", help="tune the launches of one eager pruning train step (teacher + student forward, data-gradient GEMMs) instead of the inference forward")
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
     args = ap.parse_args()
     lib = ops._lib.load()
+    if args.train:
+        log = record_train_step(args)
+        tune(args, lib, log)
+        return
     model = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
     st = model.get_structure()
     model.set_structure(ones_mask(st, dev) if args.dense else fixed_half_mask(st, dev))
@@ -104,6 +109,38 @@ def main():
         model(sample, t, ehs)
         torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    tune(args, lib, log)
+
+
+def record_train_step(args):
+    """the conv_gemm launches of one eager APTP pruning step (tools/bench_train.py's set-up)"""
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+    from diffusion_pruning_amd.train_step import PrunerStep, synthetic_batch
+    unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
+    unet.freeze()
+    st = unet.get_structure()
+    torch.manual_seed(0)
+    hn = HyperStructure(structure=st, input_dim=768, wn_flag=False, linear_bias=True).to(dev)
+    qz = StructureVectorQuantizer(n_e=8, structure=st, temperature=0.4, base=3,
+                                  depth_order=[-1, -2, 0, 1, -3, -4, 2, 3, -5, -6, 4, 5, -7, 6],
+                                  resource_aware_normalization=False, optimal_transport=True).to(dev)
+    hn.train(); qz.train()
+    step = PrunerStep(unet, hn, qz)
+    step.count_macs(64)
+    opt = torch.optim.AdamW(step.trainable_parameters(), lr=2e-4)
+    batch = synthetic_batch(args.batch, 64, dev)
+    if not args.refine:
+        ops.TUNING = {}
+    step.train_step(opt, batch)
+    ops.LAUNCH_LOG = []
+    step.train_step(opt, batch)
+    torch.cuda.synchronize()
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    return log
+
+
+def tune(args, lib, log):
     ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     counters = ops._tile_counters(dev)
     uniq = {}
@@ -164,7 +201,7 @@ def main():
               f"(t{best[1]} s{best[2]} o{best[3]} k{best[4]})  {fl / best[0] / 1e6:6.1f} TF", flush=True)
     rows.sort(reverse=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "tune_convs" + ("_dense" if args.dense else "") + ".txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "tune_convs" + ("_dense" if args.dense else "") + ("_train" if args.train else "") + ".txt"), "w") as f:
         tot_h = sum(r[3] * r[2] for r in rows)
         tot_b = sum(r[0] for r in rows)
         f.write(f"# total conv_gemm time per forward: heuristic {tot_h / 1e3:.3f} ms -> tuned {tot_b / 1e3:.3f} ms\n")

@@ -212,10 +212,10 @@ _N_COUNTERS = 1 << 16
 
 
 def _tile_counters(device):
-    """zero-initialised arrival counters shared by every split-K launch on the device (each launch leaves them zero).
+    """zero-initialised arrival counters shared by every split-K launch of one stream (each launch leaves them zero).
     Never created while a stream is capturing (the fill would only run at replay): such a call gets None and uses the
     separate reduce launch."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     buf = _counters.get(key)
     if buf is None:
         if torch.cuda.is_current_stream_capturing():
@@ -245,8 +245,10 @@ EPILOGUE = 0
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (stream-ordered reuse: kernels on one stream serialise)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.is_current_stream_capturing())
+    """Grow-only scratch buffer per (device, stream): stream-ordered reuse, kernels on one stream serialise; forwards that
+    run concurrently on different streams must not share split-K slabs or GroupNorm partials."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.is_current_stream_capturing(),
+           torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

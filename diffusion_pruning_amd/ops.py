@@ -212,10 +212,12 @@ _N_COUNTERS = 1 << 16
 
 
 def _tile_counters(device):
-    """zero-initialised arrival counters shared by every split-K launch of one stream (each launch leaves them zero).
+    """zero-initialised arrival counters shared by every split-K launch on the device (each launch leaves them zero).
     Never created while a stream is capturing (the fill would only run at replay): such a call gets None and uses the
     separate reduce launch."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    # (per device, not per stream: the buffer must exist before a stream starts capturing, and graph capture runs on a
+    # stream of its own; forwards running CONCURRENTLY on several streams would need one buffer each)
+    key = device.index if device.index is not None else torch.cuda.current_device()
     buf = _counters.get(key)
     if buf is None:
         if torch.cuda.is_current_stream_capturing():

@@ -59,3 +59,65 @@ def test_config1_half_mask_bs2_and_graph_replay(sd21, cuda):
     err = rel_l2(out.float().cpu(), ref)
     assert err <= 2e-2, err
     assert torch.equal(out, gout)          # the captured HIP graph reproduces the eager result bit for bit
+
+
+def test_headline_forward_takes_the_fused_paths_also_under_graph_capture(sd21, cuda):
+    """The headline step (bs=4, fixed 50 % mask) must actually run the fused forms -- eagerly AND while a HIP graph is being
+    captured (a missing scratch buffer or counter silently falls back to the unfused launches there): no LayerNorm kernel,
+    GroupNorm statistics from the producing GEMMs on the large maps, skip-concats as views, every shortcut convolution inside
+    conv2, the K-slices of statistics-emitting launches combined in-kernel."""
+    from diffusion_pruning_amd import ops, unet as U
+    from diffusion_pruning_amd.unet import ResnetBlock2DWidthGated
+    model, _ = sd21
+    cfg = O.SD21
+    mask = O.fixed_half_mask(cfg)
+    model.set_structure({k: [v.to(cuda) for v in vs] for k, vs in mask.items()})
+    sample, t, ehs = O.synthetic_inputs(cfg, 4, 64, seed=5)
+    s, tt, e_ = sample.to(cuda), t.to(cuda), ehs.to(cuda)
+    counts = {"ln": 0, "gn": 0, "gn_cols": 0}
+    orig_ln, orig_gn = ops.layernorm, ops.groupnorm
+
+    def ln(*a, **k):
+        counts["ln"] += 1
+        return orig_ln(*a, **k)
+
+    def gn(x, gamma, beta, groups, eps, silu, C=None, **k):
+        counts["gn"] += 1
+        if x.shape[1] * x.shape[2] >= ops.COLSTATS_MIN_HW and ops._colstats_get(x, x.shape[3] if C is None else C) is not None:
+            counts["gn_cols"] += 1
+        return orig_gn(x, gamma, beta, groups, eps, silu, C=C, **k)
+
+    n_short = sum(1 for m in model.modules() if isinstance(m, ResnetBlock2DWidthGated) and m.conv_shortcut is not None)
+    n_cat = sum(len(b.resnets) for b in model.up_blocks)
+
+    def check(log):
+        assert counts["ln"] == 0, counts
+        assert counts["gn"] == 61 and counts["gn_cols"] >= 25, counts
+        assert U.CAT_STATS == {"views": n_cat, "copies": 0}
+        assert sum(1 for r in log if r["params"].x2) == n_short == 14
+        assert len(log) == 184
+        for r in log:
+            p = r["params"]
+            if p.rowstat_out or p.colstat_out:
+                assert p.split_k == 1 or p.tile_counters, "statistics from a split launch need the in-kernel reduction"
+
+    ops.layernorm, ops.groupnorm = ln, gn
+    try:
+        with torch.no_grad():
+            U.CAT_STATS.update(views=0, copies=0)
+            ops.LAUNCH_LOG = []
+            out = model(s, tt, e_).sample
+            torch.cuda.synchronize()
+            check(ops.LAUNCH_LOG)
+            counts.update(ln=0, gn=0, gn_cols=0)
+            U.CAT_STATS.update(views=0, copies=0)
+            ops.LAUNCH_LOG = []
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                gout = model(s, tt, e_).sample
+            check(ops.LAUNCH_LOG)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(gout, out)          # deterministic kernels, same paths: bit-identical
+    finally:
+        ops.layernorm, ops.groupnorm, ops.LAUNCH_LOG = orig_ln, orig_gn, None

@@ -46,6 +46,7 @@ class ConvGemmParams(Structure):
         ("colstat_out", c_void_p), ("colstat_ld", c_int32),
         ("tile_counters", c_void_p),
         ("x2", c_void_p), ("ldx2", c_int64), ("Cin2", c_int32), ("cin2_pad", c_int32),
+        ("prefetch", c_void_p), ("prefetch_bytes", c_int64),
         ("epilogue", c_int32),
     ]
 

@@ -15,10 +15,15 @@
 // [0->1 DMA issue, 1->2 LDS reads + MFMAs, 2->3 waits + barrier], dumped by lane 0 of every wave into g_stamps.
 #ifdef APTP_STAMPS
 __device__ unsigned long long g_stamps[4096 * 4];
+// launch timeline of a wave (cycles since its first instruction): [0] prologue DMA issued, [1] first tile landed (first
+// barrier passed), [2] K loop done, [3] epilogue done and its stores drained
+__device__ unsigned long long g_phase[4096 * 4];
+#define APTP_PHASE(i) do { st_phase[i] = __builtin_readcyclecounter() - st_entry; } while (0)
 #define APTP_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
     if ((i) > 0) st_acc[(i) - 1] += t_ - st_prev; st_prev = t_; } while (0)
 #else
 #define APTP_STAMP(i) do { } while (0)
+#define APTP_PHASE(i) do { } while (0)
 #endif
 #ifndef APTP_ABLATE
 #define APTP_ABLATE 0   // timing experiments only (tools/ablate_conv.py): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no ds_read, 8 no barrier,
@@ -29,6 +34,15 @@ namespace {
 
 constexpr int BK = 64;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// Division by a launch constant as multiply-high + shift (the host computes the magic pair): the prologue / epilogue of a
+// launch decode tile and pixel coordinates with ~10 runtime divisions per lane, 25-40 instructions each on this ISA, and
+// a cycle-stamp timeline showed 1.6-2.2 us of address arithmetic before the first operand request of every launch.
+// Exact for 0 <= n < 2^31:  p = 31 + ceil(log2 d), mul = ceil(2^p / d) in [2^31, 2^32), error mul*d - 2^p < d <= 2^(p-31).
+struct FastDiv {
+  unsigned mul, shr, one;      // one = ~0u for d == 1 (mul = 0, shr = 0: q = n)
+  __device__ __forceinline__ int div(int n) const { return (int)((__umulhi((unsigned)n, mul) + ((unsigned)n & one)) >> shr); }
+};
 
 struct KParams {
   const __bf16* x; int64_t ldx;
@@ -51,11 +65,14 @@ struct KParams {
   int M, HW, Nout;          // Nout = logical output columns (N/2 for GEGLU)
   int64_t ws_ld;            // workspace row stride (floats)
   int order;                // workgroup -> tile order (decode_block): 0 legacy, 1 weight-major, 2 activation-major
+  const char* pf_ptr; int64_t pf_bytes;   // operand of the NEXT launch to pull towards the Infinity Cache (prefetch_next)
   int* counters;            // in-kernel split-K: one arrival counter per output tile (zero on entry, left zero)
   float* cstat_out; int cstat_ld;   // per-(row block, channel) (sum, sumsq) of the stored outputs: GroupNorm statistics
   int epi16;                // 1: bf16 output (and residual / depth_in) rows are 16-byte aligned -> coalesced epilogue
   float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
   const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
+  FastDiv fd_hw, fd_wout;                    // / HW, / Wout (per lane)
+  FastDiv fd_tm, fd_tn, fd_sk, fd_perm, fd_tmn;   // decode_block: / tiles_m, / tiles_n, / split_k, / (tiles_n * split_k), / (tiles_m * tiles_n)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -74,10 +91,10 @@ struct KParams {
 __device__ __forceinline__ void decode_block(const KParams& p, int tiles_m, int tiles_n, int& tm, int& tn, int& kz) {
   const int L = blockIdx.x;
   if (p.order == 0) {
-    const int t = L % (tiles_m * tiles_n);
-    kz = L / (tiles_m * tiles_n);
-    tn = t % tiles_n;
-    tm = t / tiles_n;
+    kz = p.fd_tmn.div(L);
+    const int t = L - kz * (tiles_m * tiles_n);
+    tm = p.fd_tn.div(t);
+    tn = t - tm * tiles_n;
     return;
   }
   const int T = gridDim.x;
@@ -85,16 +102,16 @@ __device__ __forceinline__ void decode_block(const KParams& p, int tiles_m, int 
   const int qq = T >> 3, r = T & 7;
   const int q = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + j;
   if (p.order == 1) {
-    tm = q % tiles_m;
-    const int w = q / tiles_m;          // weight slice: K-slice fastest, so an XCD's slices of one N-tile are adjacent
-    kz = w % p.split_k;
-    tn = w / p.split_k;
+    const int w = p.fd_tm.div(q);       // weight slice: K-slice fastest, so an XCD's slices of one N-tile are adjacent
+    tm = q - w * tiles_m;
+    tn = p.fd_sk.div(w);
+    kz = w - tn * p.split_k;
   } else {
     const int per_m = tiles_n * p.split_k;
-    tm = q / per_m;
+    tm = p.fd_perm.div(q);
     const int rest = q - tm * per_m;
-    tn = rest % tiles_n;
-    kz = rest / tiles_n;
+    kz = p.fd_tn.div(rest);
+    tn = rest - kz * tiles_n;
   }
 }
 
@@ -217,12 +234,12 @@ __device__ __forceinline__ void epilogue_quad(const KParams& p, int m, const Row
 }
 
 __device__ __forceinline__ void row_info(const KParams& p, int m, RowCtx& rc) {
-  rc.b = m / p.HW;
+  rc.b = p.fd_hw.div(m);
   rc.cls = 4;
   rc.mean = 0.f; rc.rstd = 1.f;
   if (p.corr) {
     const int rem = m - rc.b * p.HW;
-    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+    const int oy = p.fd_wout.div(rem), ox = rem - oy * p.Wout;
     const int rr = oy == 0 ? 0 : (oy == p.Hout - 1 ? 2 : 1);
     const int cc = ox == 0 ? 0 : (ox == p.Wout - 1 ? 2 : 1);
     rc.cls = rr * 3 + cc;
@@ -471,7 +488,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
         for (int e = 0; e < 8; ++e) v[e] += f[e];
       }
       if (p.depth && !(APTP_ABLATE & 64)) {
-        const float d = p.depth[((m2 < p.M ? m2 : p.M - 1) / p.HW) % p.depth_B];
+        const float d = p.depth[p.fd_hw.div(m2 < p.M ? m2 : p.M - 1) % p.depth_B];
         float f[8];
         union { u32x4 v; uint4 s; } cv; cv.v = rdin[ps];
         unpack_bf16x8(cv.s, f);
@@ -618,6 +635,26 @@ __device__ __forceinline__ bool splitk_combine(const KParams& p, f32x4 (&acc)[MF
   return true;
 }
 
+// Cold-weight prefetch (LDS-DMA kernels).  Every weight is read once per forward and the forward's working set exceeds
+// the 256 MB Infinity Cache, so each launch starts on HBM-cold weights.  With pf_ptr set, every
+// workgroup touches its 1/gridDim slice of the NEXT launch's weights at kernel entry, one dword per 64-byte line.
+// Measured on the headline forward (APTP_PREFETCH=1): within box noise of not doing it (178.7 vs 178.1 steps/s), and 4 %
+// slower when issued after the epilogue, where the wave's end waits for the loads -- the cold cost is latency per
+// K-step, which a warmer memory-side cache does not shorten.  Off by default; kept for the next experiment.
+__device__ __forceinline__ void prefetch_next(const KParams& p, int tid, int nt, unsigned* scratch) {
+  if (!p.pf_ptr) return;
+  // LDS-DMA loads into a 256-byte scratch row: no VGPRs, nothing waits on them but the counted vmcnt of the main loop
+  // (in-order retirement: they were issued before the first operand stage)
+  const int64_t lines = p.pf_bytes >> 6;
+  const int64_t per = (lines + gridDim.x - 1) / gridDim.x;
+  const int64_t l0 = (int64_t)blockIdx.x * per;
+  const int64_t l1 = l0 + per < lines ? l0 + per : lines;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  for (int64_t l = l0 + tid; l < l1; l += nt)
+    __builtin_amdgcn_global_load_lds((gptr)(p.pf_ptr + l * 64), (lptr)scratch, 4, 0, 0);
+}
+
 // picks the epilogue form (wave-uniform): the coalesced one needs 16-byte aligned bf16 rows (p.epi16, set on the host)
 template <int NW, int MF, int NF, int WTM, int WTN, int WN>
 __device__ __forceinline__ void run_epilogue(const KParams& p, f32x4 (&acc)[MF][NF], int m0, int n0, int tn, int wm, int wn, int lane,
@@ -659,8 +696,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   int tm, tn, kz;
   decode_block(p, tiles_m, tiles_n, tm, tn, kz);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
-  const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+  const int kt_begin = p.fd_sk.div(p.nK * kz);            // (nK * split_k < 2^31: checked on the host)
+  const int kt_end = p.fd_sk.div(p.nK * (kz + 1));
   LnRaw<MF> ln_raw;
   ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw);
 
@@ -677,8 +714,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   for (int i = 0; i < A_PASS; ++i) {
     const int m = m0 + rowbase + 32 * i;
     if (m < p.M) {
-      const int b = m / p.HW, rem = m - b * p.HW;
-      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      const int b = p.fd_hw.div(m), rem = m - b * p.HW;
+      const int oy = p.fd_wout.div(rem), ox = rem - oy * p.Wout;
       a_iy0[i] = oy * p.stride - p.pad;
       a_ix0[i] = ox * p.stride - p.pad;
       a_pix0[i] = b * p.Hin * p.Win;
@@ -697,10 +734,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   // K-iteration state of the NEXT tile to load (l_ky == KH: the x2 segment after the filter taps)
   const int nk_taps = p.KH * p.KW * p.ncc;
   int l_kt = kt_begin;
-  int l_tap = kt_begin / p.ncc;
-  int l_cc = kt_begin - l_tap * p.ncc;
-  int l_ky = l_tap / p.KW;
-  int l_kx = l_tap - l_ky * p.KW;
+  int l_tap = 0, l_cc = 0, l_ky = 0, l_kx = 0;
+  if (kt_begin != 0) {                   // (workgroup-uniform; only K-slices past the first pay the divisions)
+    l_tap = kt_begin / p.ncc;
+    l_cc = kt_begin - l_tap * p.ncc;
+    l_ky = l_tap / p.KW;
+    l_kx = l_tap - l_ky * p.KW;
+  }
   if (kt_begin >= nk_taps) { l_ky = p.KH; l_kx = 0; l_cc = kt_begin - nk_taps; }
 
   u32x4 ra[A_PASS], rb[B_PASS];
@@ -854,12 +894,19 @@ __device__ uint4 g_zero_page[512];
 // Address generation is incremental: the per-row source pointer is recomputed only when the filter tap changes (every
 // cin_pad/64 K-steps) and otherwise advanced by 128 B per K-step; PMC counters showed the previous per-step
 // recomputation (~115 VALU instructions per K-step per wave) made the loop VALU-issue-bound at 24 % MFMA utilisation.
-template <int BM, int BN, int WM, int WN, int STAGES, bool PP = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KParams p) {
-  constexpr int NW = WM * WN;                 // waves per workgroup: 4 (256 threads) or 8 (512 threads)
-  constexpr int NT = NW * 64;
+// KS = 2: the workgroup carries TWO copies of the WM x WN wave grid; copy ks multiplies the ks-th 32-wide half of every
+//         64-wide K-tile (intra-workgroup split-K).  All 2*WM*WN waves share the LDS-DMA of the tile; after the K loop copy 1
+//         hands its accumulators to copy 0 through LDS and retires (s_barrier counts surviving waves only), copy 0 runs the
+//         epilogue.  Twice the waves per SIMD on the same operand traffic, for the small tiles whose waves otherwise sit
+//         alone on their SIMD between DMA issue, LDS reads and MFMAs.
+template <int BM, int BN, int WM, int WN, int STAGES, bool PP = false, int KU = 1, int KS = 1>
+__global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const KParams p) {
+  constexpr int NW = WM * WN;                 // waves of one compute grid
+  constexpr int NWA = NW * KS;                // waves per workgroup: 4 (256 threads) or 8 (512 threads)
+  constexpr int NT = NWA * 64;
   constexpr int RPP = NT / 8;                 // tile rows covered by one LDS-DMA pass of the whole workgroup
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  static_assert(NWA == 4 || NWA == 8, "4 or 8 waves per workgroup");
+  static_assert(KS == 1 || (KS == 2 && !PP), "intra-workgroup K split: two copies, ring schedules only");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MF = WTM / 16, NF = WTN / 16;
   constexpr int A_PASS = (BM + RPP - 1) / RPP, B_PASS = (BN + RPP - 1) / RPP;
@@ -868,17 +915,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   __shared__ __attribute__((aligned(16))) __bf16 smem[STAGES * (BM + BN) * BK];
   __bf16* As = smem;
   __bf16* Bs = smem + STAGES * BM * BK;
+#ifdef APTP_STAMPS
+  const unsigned long long st_entry = __builtin_readcyclecounter();
+  unsigned long long st_phase[4] = {0, 0, 0, 0};
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases stay scalar
-  const int wm = wave / WN, wn = wave % WN;
+  const int ks = KS == 2 ? wave / NW : 0, cw = KS == 2 ? wave % NW : wave;   // compute-grid copy, wave within it
+  const int wm = cw / WN, wn = cw % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   int tm, tn, kz;
   decode_block(p, tiles_m, tiles_n, tm, tn, kz);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
-  const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+  const int kt_begin = p.fd_sk.div(p.nK * kz);            // (nK * split_k < 2^31: checked on the host)
+  const int kt_end = p.fd_sk.div(p.nK * (kz + 1));
+  __shared__ unsigned pf_scratch[64];
+  prefetch_next(p, tid, NT, pf_scratch);
   LnRaw<MF> ln_raw;
   ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw);
 
@@ -894,8 +948,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
   for (int i = 0; i < A_PASS; ++i) {
     const int m = m0 + rowbase + RPP * i;
     if (m < p.M && rowbase + RPP * i < BM) {
-      const int b = m / p.HW, rem = m - b * p.HW;
-      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      const int b = p.fd_hw.div(m), rem = m - b * p.HW;
+      const int oy = p.fd_wout.div(rem), ox = rem - oy * p.Wout;
       a_iy0[i] = oy * p.stride - p.pad;
       a_ix0[i] = ox * p.stride - p.pad;
       a_pix0[i] = b * p.Hin * p.Win;
@@ -907,10 +961,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
 
   // (l_ky == KH: the x2 segment after the filter taps, see KParams)
   const int nk_taps = p.KH * p.KW * p.ncc;
-  int l_tap = kt_begin / p.ncc;
-  int l_cc = kt_begin - l_tap * p.ncc;
-  int l_ky = l_tap / p.KW;
-  int l_kx = l_tap - l_ky * p.KW;
+  int l_tap = 0, l_cc = 0, l_ky = 0, l_kx = 0;
+  if (kt_begin != 0) {                   // (workgroup-uniform; only K-slices past the first pay the divisions)
+    l_tap = kt_begin / p.ncc;
+    l_cc = kt_begin - l_tap * p.ncc;
+    l_ky = l_tap / p.KW;
+    l_kx = l_tap - l_ky * p.KW;
+  }
   if (kt_begin >= nk_taps) { l_ky = p.KH; l_kx = 0; l_cc = kt_begin - nk_taps; }
 
   const char* a_ptr[A_PASS];
@@ -1005,7 +1062,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
 #endif
   auto compute = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s0 = 0; s0 < 2 / KS; ++s0) {
+      const int s = KS == 2 ? ks : s0;          // 32-wide half of the K-tile
       bf16x8 af[MF], wf[NF];
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
@@ -1055,7 +1113,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     //   WAR: tile k+D lands in the stage of tile k+D-S = k-2 (S = D+2), last read by group 1 in its C(k-2), which ends
     //        one barrier before group 0's L(k) starts.  (S = D+1 would let group 0's DMA overwrite the stage group 1 is
     //        still reading in the same slot.)
-    static_assert(NW == 8 && STAGES >= 3, "ping-pong needs 8 waves and a ring of >= 3 stages");
+    static_assert(NWA == 8 && KS == 1 && STAGES >= 3, "ping-pong needs 8 waves and a ring of >= 3 stages");
     static_assert(BM % RPP == 0, "ring: the activation tile must be whole row passes");
     constexpr int D = STAGES - 2;
     constexpr int A_FULL = BM / RPP, B_FULL = BN / RPP;
@@ -1120,6 +1178,52 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
       }
     }
   } else
+  if constexpr (KU == 2) {
+    // Two K-tiles per synchronisation point (an effective K-step of 128): iteration i issues tiles 2i+D and 2i+D+1 into the
+    // two stages read in iteration i-1, runs the MFMAs of tiles 2i and 2i+1, waits until tiles 2i+2 and 2i+3 have landed
+    // (D-2 newer tiles stay in flight) and meets ONE barrier: half the s_waitcnt / s_barrier stops of the ring above.
+    static_assert(STAGES >= 4 && STAGES % 2 == 0, "pairs of stages");
+    constexpr int D = STAGES - 2;
+    constexpr int A_FULL = BM / RPP, B_FULL = BN / RPP;
+    constexpr int NLD_LO = A_FULL + B_FULL, NLD_HI = A_PASS + B_PASS;
+    static_assert(BM % RPP == 0, "ring: the activation tile must be whole row passes");
+    static_assert(NLD_HI * (D - 2) <= 63, "vmcnt immediate");
+    const bool hi = (NLD_HI != NLD_LO) && (wave * 8 + RPP * (B_PASS - 1) < BN);   // wave-uniform
+    const int n = kt_end - kt_begin;
+    if (n > 0) {
+      const int pre = n < D ? n : D;
+      for (int t = 0; t < pre; ++t) issue_tile(t);
+      ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
+      if (pre == D && D > 2) {   // tiles 0 and 1 landed, D-2 tiles still in flight
+        if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 2)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int cur = 0, nxt = D;
+      for (int kt = 0; kt < n; kt += 2) {
+        const int ni = n - (kt + D);          // tiles left to request: two per iteration while >= 2
+        if (ni >= 1) issue_tile(nxt);
+        if (ni >= 2) issue_tile(nxt + 1);
+        compute(cur);
+        if (kt + 1 < n) compute(cur + 1);
+        asm volatile("" ::: "memory");
+        if (ni >= 2 && D > 2) {
+          if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 2)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 2)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (D == 2: plain double buffering of 128-wide steps) / tail
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur = cur + 2 == STAGES ? 0 : cur + 2;
+        nxt = nxt + 2 == STAGES ? 0 : nxt + 2;
+      }
+    }
+  } else
   if constexpr (STAGES == 2) {
     if (kt_begin < kt_end) {
       issue_tile(0);
@@ -1156,6 +1260,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     if (n > 0) {
       const int pre = n < D ? n : D;
       for (int t = 0; t < pre; ++t) issue_tile(t);
+      APTP_PHASE(0);
       ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
       if (pre == D) {   // tile 0 landed, D-1 tiles still in flight
         if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
@@ -1165,6 +1270,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      APTP_PHASE(1);
       int cur = 0, nxt = D;          // stage of tile kt, stage of tile kt+D
       for (int kt = 0; kt < n; ++kt) {
         const bool issue = kt + D < n;
@@ -1192,6 +1298,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     }
   }
 
+  APTP_PHASE(2);
 #ifdef APTP_STAMPS
   if (lane == 0 && kz == 0) {
     const int slot = (blockIdx.x * NW + wave) & 4095;
@@ -1199,8 +1306,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     g_stamps[slot * 4 + 3] = __builtin_readcyclecounter() - st_begin;
   }
 #endif
+  if constexpr (KS == 2) {
+    // every path above ends on a barrier with the DMA drained and the fragment reads done: the stages are free
+    f32x4* xch = reinterpret_cast<f32x4*>(smem) + cw * (MF * NF * 64) + lane;
+    if (ks == 1) {
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) xch[(i * NF + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (ks == 1) return;                   // (wave-uniform; later barriers count the surviving waves)
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] += xch[(i * NF + j) * 64];
+  }
   if (p.split_k > 1 && p.counters) {
-    if (!splitk_combine<NT, MF, NF>(p, acc, tm * tiles_n + tn, kz, tid, reinterpret_cast<int*>(smem))) return;
+    if (!splitk_combine<NW * 64, MF, NF>(p, acc, tm * tiles_n + tn, kz, tid, reinterpret_cast<int*>(smem))) return;
     ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw, true);
     ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd, true);
   } else
@@ -1221,7 +1344,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_dma_kernel(const KPara
     return;
   }
   static_assert(NW * 16 * (WTN + 4) * 4 <= (int)sizeof(smem), "epilogue transpose buffer");
-  run_epilogue<NW, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, wave, ln_mean, ln_rstd, smem);
+  static_assert(KS == 1 || NW * MF * NF * 64 * 16 <= (int)sizeof(smem), "accumulator hand-over buffer");
+  run_epilogue<NW, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, cw, ln_mean, ln_rstd, smem);
+#ifdef APTP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  APTP_PHASE(3);
+  if (lane == 0 && kz == 0) {
+    const int slot = (blockIdx.x * NW + wave) & 4095;
+    for (int i = 0; i < 4; ++i) g_phase[slot * 4 + i] = st_phase[i];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1257,14 +1389,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KParams p) {
   int tm, tn, kz;
   decode_block(p, tiles_m, tiles_n, tm, tn, kz);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_begin = (int)(((int64_t)p.nK * kz) / p.split_k);
-  const int kt_end = (int)(((int64_t)p.nK * (kz + 1)) / p.split_k);
+  const int kt_begin = p.fd_sk.div(p.nK * kz);            // (nK * split_k < 2^31: checked on the host)
+  const int kt_end = p.fd_sk.div(p.nK * (kz + 1));
   LnRaw<MF> ln_raw;
   ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw);
 
   const int W = p.Wout, PW = W + 2, R = BM / W;
   const int prows = (R + 2) * PW;
-  const int b_img = m0 / p.HW, oy0 = (m0 - b_img * p.HW) / W;
+  const int b_img = p.fd_hw.div(m0), oy0 = (m0 - b_img * p.HW) / W;
 
   // ---- patch source pointers: row prow = (pr, pc) of the patch <-> input pixel (oy0 - 1 + pr, pc - 1) ---------------------
   const int rowbase = tid >> 3;
@@ -1496,9 +1628,25 @@ const TileCfg kTiles[] = {
     {128, 128, 4, 8}, {128, 128, 4, 8}, {256, 128, 2, 8}, {128, 160, 2, 8}, {128, 160, 2, 8}, {128, 128, 4, 8},
     {128, 128, 4, 8}, {64, 160, 2, 8}, {64, 128, 4, 8}, {64, 160, 2, 8}, {128, 64, 2, 8}, {256, 128, 2, 8},
     {128, 256, 4, 8},
-    {128, 160, 2, 8}, {128, 128, 2, 8}};      // 43, 44: 3x3 halo-in-LDS kernel (conv3x3_halo_kernel)
-constexpr int kNumTiles = 45;
+    {128, 160, 2, 8}, {128, 128, 2, 8},       // 43, 44: 3x3 halo-in-LDS kernel (conv3x3_halo_kernel)
+    {64, 64, 2, 4}, {64, 64, 2, 4}, {64, 128, 2, 4}, {128, 64, 2, 4},   // 45-48: deep rings for latency-bound small-M launches
+    {64, 64, 2, 4}, {64, 64, 2, 4}, {64, 128, 2, 4}, {64, 128, 2, 4}, {128, 64, 2, 4}, {128, 128, 2, 4}, {64, 160, 2, 4},
+    {128, 160, 2, 8}, {128, 128, 4, 8},                                  // 49-57: two K-tiles per barrier
+    {64, 64, 2, 4}, {64, 64, 2, 4}, {64, 128, 2, 4}, {64, 128, 2, 4}, {128, 64, 2, 4}, {128, 128, 2, 4}};   // 58-63: intra-workgroup K split (compute grid 2 x 2)
+constexpr int kNumTiles = 64;
 static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == kNumTiles, "tile table");
+
+FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  if (d <= 1) { f.mul = 0; f.shr = 0; f.one = ~0u; return f; }
+  int l = 0;
+  while ((1ll << l) < d) ++l;                       // ceil(log2 d)
+  const int p = 31 + l;
+  f.mul = (unsigned)(((1ull << p) + (unsigned)d - 1) / (unsigned)d);
+  f.shr = (unsigned)(p - 32);
+  f.one = 0;
+  return f;
+}
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
   if (p->tile != APTP_TILE_AUTO) return p->tile;
@@ -1586,6 +1734,8 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
                               p->ln_slots % 2 == 0 && ((uintptr_t)p->ln_stats % 16) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
              "conv_gemm: folded LayerNorm needs ln_colsum [N], ln_slots > 0, ln_C > 0 and a 1x1 filter");
   k.counters = p->tile_counters;
+  k.pf_ptr = ((uintptr_t)p->prefetch & 3) ? nullptr : (const char*)p->prefetch;   // dword loads
+  k.pf_bytes = k.pf_ptr ? p->prefetch_bytes : 0;
   k.cstat_out = p->colstat_out; k.cstat_ld = p->colstat_ld;
   k.epi16 = !p->out_f32 && p->ldy % 8 == 0 && ((uintptr_t)p->y % 16) == 0 && nout % 8 == 0 &&
             (!p->residual || (p->ldres % 8 == 0 && ((uintptr_t)p->residual % 16) == 0)) &&
@@ -1620,6 +1770,22 @@ void launch_tile_dma8(const KParams& k, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(512), 0, s, k);
 }
 
+// two K-tiles per barrier (KU = 2, see the kernel): 4 waves (2 x 2) or 8 waves
+template <int BM, int BN, int WM, int WN, int STAGES>
+void launch_tile_ku2(const KParams& k, hipStream_t s) {
+  const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
+  dim3 grid(tiles * k.split_k, 1, 1);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, false, 2>), grid, dim3(WM * WN * 64), 0, s, k);
+}
+
+// intra-workgroup K split (KS = 2, see the kernel): 2 x (2 x 2) waves
+template <int BM, int BN, int STAGES>
+void launch_tile_ks2(const KParams& k, hipStream_t s) {
+  const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
+  dim3 grid(tiles * k.split_k, 1, 1);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, 2, STAGES, false, 1, 2>), grid, dim3(512), 0, s, k);
+}
+
 // 8-wave ping-pong schedule (see the kernel): wave grid WM x WN, STAGES-deep ring
 template <int BM, int BN, int WM, int WN, int STAGES>
 void launch_tile_pp(const KParams& k, hipStream_t s) {
@@ -1633,6 +1799,9 @@ void launch_tile_pp(const KParams& k, hipStream_t s) {
 #ifdef APTP_STAMPS
 extern "C" int aptp_debug_read_stamps(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int aptp_debug_read_phases(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
 }
 #endif
 
@@ -1721,6 +1890,13 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     aptp_set_error("conv_gemm: GEGLU cannot use a 160-wide tile");
     return APTP_EINVAL;
   }
+  {
+    const int tiles_m = (k.M + kTiles[t].bm - 1) / kTiles[t].bm, tiles_n = (k.N + kTiles[t].bn - 1) / kTiles[t].bn;
+    APTP_CHECK((int64_t)tiles_m * tiles_n * k.split_k < (1ll << 31) && (int64_t)k.nK * (k.split_k + 1) < (1ll << 31), "conv_gemm: grid too large");
+    k.fd_hw = make_fastdiv(k.HW); k.fd_wout = make_fastdiv(k.Wout);
+    k.fd_tm = make_fastdiv(tiles_m); k.fd_tn = make_fastdiv(tiles_n); k.fd_sk = make_fastdiv(k.split_k);
+    k.fd_perm = make_fastdiv(tiles_n * k.split_k); k.fd_tmn = make_fastdiv(tiles_m * tiles_n);
+  }
   switch (t) {
     case APTP_TILE_128x128: launch_tile<128, 128>(k, s); break;
     case APTP_TILE_128x160: launch_tile<128, 160>(k, s); break;
@@ -1764,6 +1940,25 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_PP4_128x64: launch_tile_pp<128, 64, 4, 2, 4>(k, s); break;
     case APTP_TILE_PP3_256x128: launch_tile_pp<256, 128, 4, 2, 3>(k, s); break;
     case APTP_TILE_PP3_128x256: launch_tile_pp<128, 256, 2, 4, 3>(k, s); break;
+    case APTP_TILE_DMA6_64x64: launch_tile_dma<64, 64, 6>(k, s); break;
+    case APTP_TILE_DMA8S_64x64: launch_tile_dma<64, 64, 8>(k, s); break;
+    case APTP_TILE_DMA6_64x128: launch_tile_dma<64, 128, 6>(k, s); break;
+    case APTP_TILE_DMA6_128x64: launch_tile_dma<128, 64, 6>(k, s); break;
+    case APTP_TILE_KU2S4_64x64: launch_tile_ku2<64, 64, 2, 2, 4>(k, s); break;
+    case APTP_TILE_KU2S6_64x64: launch_tile_ku2<64, 64, 2, 2, 6>(k, s); break;
+    case APTP_TILE_KU2S4_64x128: launch_tile_ku2<64, 128, 2, 2, 4>(k, s); break;
+    case APTP_TILE_KU2S6_64x128: launch_tile_ku2<64, 128, 2, 2, 6>(k, s); break;
+    case APTP_TILE_KU2S4_128x64: launch_tile_ku2<128, 64, 2, 2, 4>(k, s); break;
+    case APTP_TILE_KU2S4_128x128: launch_tile_ku2<128, 128, 2, 2, 4>(k, s); break;
+    case APTP_TILE_KU2S4_64x160: launch_tile_ku2<64, 160, 2, 2, 4>(k, s); break;
+    case APTP_TILE_KU2S4_128x160: launch_tile_ku2<128, 160, 4, 2, 4>(k, s); break;
+    case APTP_TILE_KU2S4_128x128W8: launch_tile_ku2<128, 128, 2, 4, 4>(k, s); break;
+    case APTP_TILE_KS2S3_64x64: launch_tile_ks2<64, 64, 3>(k, s); break;
+    case APTP_TILE_KS2S4_64x64: launch_tile_ks2<64, 64, 4>(k, s); break;
+    case APTP_TILE_KS2S3_64x128: launch_tile_ks2<64, 128, 3>(k, s); break;
+    case APTP_TILE_KS2S4_64x128: launch_tile_ks2<64, 128, 4>(k, s); break;
+    case APTP_TILE_KS2S3_128x64: launch_tile_ks2<128, 64, 3>(k, s); break;
+    case APTP_TILE_KS2S3_128x128: launch_tile_ks2<128, 128, 3>(k, s); break;
     case APTP_TILE_HALO_128x160:
     case APTP_TILE_HALO_128x128: {
       // whole image rows per tile, the patch (R+2) x (W+2) must fit the 264-row LDS image, no second operand

@@ -8,6 +8,7 @@ so the whole forward can be captured into a HIP graph with ``torch.cuda.graph``.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -305,13 +306,44 @@ def _colstats_get(x: torch.Tensor, C: int):
     return segs
 
 
+class _PrefetchPlan:
+    """Order in which one forward reads its packed weights.  The first forward records it; later forwards hand launch i
+    the weights of launch i+1 as AptpConvGemmParams.prefetch.  A forward whose order differs from the recorded one
+    (another batch of expert masks, other packs) re-records from the point of divergence."""
+
+    def __init__(self):
+        self.seq = []
+        self.i = 0
+
+    def begin(self):
+        self.i = 0
+
+    def step(self, w):
+        i, self.i = self.i, self.i + 1
+        if i < len(self.seq) and self.seq[i] is w:
+            nxt = self.seq[i + 1] if i + 1 < len(self.seq) else None
+        else:
+            del self.seq[i:]
+            self.seq.append(w)
+            nxt = None
+        if nxt is not None and nxt.numel() * nxt.element_size() < PREFETCH_MIN_BYTES:
+            return None
+        return nxt
+
+
+_prefetch_plan = _PrefetchPlan()
+PREFETCH_WEIGHTS = os.environ.get("APTP_PREFETCH", "0") == "1"
+PREFETCH_MIN_BYTES = int(os.environ.get("APTP_PREFETCH_MIN", "0"))
+
+
 def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None, ups: int = 0,
               out: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
               colgate: Optional[torch.Tensor] = None, gate_group: int = 0, act: int = ACT_NONE,
               corr: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
               out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0,
-              rowstats: bool = False, ln=None, colstats: bool = False, x2: Optional[torch.Tensor] = None):
+              rowstats: bool = False, ln=None, colstats: bool = False, x2: Optional[torch.Tensor] = None,
+              prefetch: Optional[torch.Tensor] = None):
     """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites.
     rowstats: also emit the per-row (sum, sumsq) partials of y a following folded LayerNorm needs; returns (y, stats)
     with stats fp32 [slots / 2, M, 4] (two (sum, sumsq) slots per element), or (y, None) when this launch is split along K (the caller then normalises with
@@ -378,6 +410,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.tile = tile
     p.order = order
     p.epilogue = EPILOGUE
+    if PREFETCH_WEIGHTS and prefetch is None:
+        prefetch = _prefetch_plan.step(pw.w)
+    if prefetch is not None:
+        p.prefetch, p.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     p.split_k = 1
     in_kernel = None                 # split-K form: tuned per shape; untuned shapes combine in-kernel up to 4 slices
     explicit_split = split_k is not None

@@ -1550,6 +1550,7 @@ class UNet2DConditionModelGated(nn.Module):
         misc = self._misc_packs(dev)
         bp = self._batched_packs(dev)
         out_dtype = sample.dtype
+        ops._prefetch_plan.begin()
 
         # 1. time (unet_2d_conditional.py:1497-1519): sinusoid [cos|sin] -> Linear -> SiLU -> Linear; the SiLU that
         # every resnet applies to emb (blocks.py:335) is fused into linear_2's epilogue.

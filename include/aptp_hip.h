@@ -121,6 +121,12 @@ typedef struct {
   const void* x2;
   int64_t ldx2;
   int32_t Cin2, cin2_pad;
+  /* optional: [prefetch, prefetch + prefetch_bytes) = an operand of the NEXT launch (its packed weights).  Workgroups that
+   * have finished their tile touch it (one dword per 64-byte line, results discarded) so that it is on its way into the
+   * 256 MB Infinity Cache when the next launch starts: every weight of the U-Net is read once per forward and would
+   * otherwise be fetched HBM-cold. */
+  const void* prefetch;
+  int64_t prefetch_bytes;
   int32_t epilogue;     /* 0 = auto (coalesced 16-byte stores through an LDS transpose when y / residual / depth_in rows are
                          * 16-byte aligned), 1 = force the accumulator-layout epilogue (testing / tuning) */
 } AptpConvGemmParams;
@@ -147,7 +153,19 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        APTP_TILE_PP3_256x128 = 41, APTP_TILE_PP3_128x256 = 42,
        /* 3x3 / stride-1 / pad-1 only, image width 16 / 32 / 64: the input halo of 128 output pixels (whole image rows) is
         * kept in LDS across the nine taps, weights stream through a 4-stage ring (8 waves) */
-       APTP_TILE_HALO_128x160 = 43, APTP_TILE_HALO_128x128 = 44 };
+       APTP_TILE_HALO_128x160 = 43, APTP_TILE_HALO_128x128 = 44,
+       /* LDS-DMA, 4 waves, 6- or 8-stage ring (96-144 KB of LDS, one workgroup per CU): launches with few workgroups and a
+        * long K whose time is K-steps x operand latency / tiles in flight */
+       APTP_TILE_DMA6_64x64 = 45, APTP_TILE_DMA8S_64x64 = 46, APTP_TILE_DMA6_64x128 = 47, APTP_TILE_DMA6_128x64 = 48,
+       /* LDS-DMA ring with TWO 64-wide K-tiles per barrier (an effective K-step of 128), 4- or 6-stage ring; 4 waves, the
+        * last two 8 waves */
+       APTP_TILE_KU2S4_64x64 = 49, APTP_TILE_KU2S6_64x64 = 50, APTP_TILE_KU2S4_64x128 = 51, APTP_TILE_KU2S6_64x128 = 52,
+       APTP_TILE_KU2S4_128x64 = 53, APTP_TILE_KU2S4_128x128 = 54, APTP_TILE_KU2S4_64x160 = 55, APTP_TILE_KU2S4_128x160 = 56,
+       APTP_TILE_KU2S4_128x128W8 = 57,
+       /* LDS-DMA ring, 8 waves as TWO copies of a 2 x 2 wave grid: copy 0 / 1 multiplies the first / second 32-wide half
+        * of every K-tile (intra-workgroup split-K, summed through LDS before the epilogue); 3- or 4-stage ring */
+       APTP_TILE_KS2S3_64x64 = 58, APTP_TILE_KS2S4_64x64 = 59, APTP_TILE_KS2S3_64x128 = 60, APTP_TILE_KS2S4_64x128 = 61,
+       APTP_TILE_KS2S3_128x64 = 62, APTP_TILE_KS2S3_128x128 = 63 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

@@ -18,7 +18,7 @@ def _bf(x):
 
 def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colgate=None, gate_group=0, act=ACT_NONE,
               corr=None, residual=None, depth=None, depth_in=None, out_f32=False, split_k=None, tile=0,
-              rowstats=False, ln=None, colstats=False, x2=None):
+              rowstats=False, ln=None, colstats=False, x2=None, prefetch=None):
     B, H, W, C = x.shape
     assert C == pw.Cin and x.dtype == torch.bfloat16
     if pad is None:

@@ -102,6 +102,47 @@ CONV_CASES = [
     (4, 16, 16, 72, 200, 3, 1, 0, 43, 1),
     (1, 64, 64, 640, 128, 3, 1, 0, 44, 4),
     (3, 32, 32, 1280, 320, 3, 1, 0, 43, 7),
+    # 6- / 8-stage rings (tiles 45..48): K shorter than, equal to and longer than the ring; split-K slices shorter than the ring
+    (2, 16, 16, 128, 128, 1, 1, 0, 45, 1),
+    (2, 16, 16, 384, 200, 1, 1, 0, 46, 1),
+    (1, 16, 16, 1280, 1280, 1, 1, 0, 46, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 46, 5),
+    (3, 7, 5, 72, 40, 3, 1, 0, 45, 1),
+    (2, 16, 16, 640, 320, 1, 1, 0, 47, 1),
+    (1, 8, 8, 1280, 640, 3, 1, 0, 47, 4),
+    (2, 32, 32, 320, 72, 3, 1, 0, 48, 1),
+    (2, 16, 16, 512, 128, 1, 1, 0, 48, 2),
+    # two K-tiles per barrier (tiles 49..57): odd and even tile counts, K shorter than the ring, split-K slices of 1..3 tiles, tails
+    (2, 16, 16, 64, 64, 1, 1, 0, 49, 1),       # one K-tile
+    (2, 16, 16, 128, 128, 1, 1, 0, 49, 1),     # two
+    (2, 16, 16, 192, 128, 1, 1, 0, 50, 1),     # three (odd) on the 6-stage ring
+    (2, 16, 16, 320, 200, 1, 1, 0, 50, 1),     # five = D + 1
+    (1, 16, 16, 1280, 1280, 1, 1, 0, 50, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 49, 5),
+    (3, 7, 5, 72, 40, 3, 1, 0, 49, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 52, 4),
+    (2, 16, 16, 640, 320, 1, 1, 0, 51, 1),
+    (1, 8, 8, 1280, 640, 3, 1, 0, 52, 4),
+    (2, 32, 32, 320, 72, 3, 1, 0, 53, 1),
+    (2, 16, 16, 128, 128, 3, 2, 0, 54, 1),
+    (2, 8, 8, 128, 128, 3, 1, 1, 54, 3),
+    (2, 32, 32, 160, 320, 3, 1, 0, 55, 1),
+    (4, 64, 64, 320, 320, 3, 1, 0, 56, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 56, 2),
+    (4, 32, 32, 1280, 640, 3, 1, 0, 57, 3),
+    (3, 7, 5, 72, 40, 3, 1, 0, 57, 1),
+    # intra-workgroup K split (tiles 58..63): copy 1 hands its accumulators over through LDS and retires before the epilogue
+    (2, 16, 16, 64, 64, 1, 1, 0, 58, 1),
+    (2, 16, 16, 192, 128, 1, 1, 0, 59, 1),
+    (1, 16, 16, 1280, 1280, 1, 1, 0, 58, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 59, 5),
+    (3, 7, 5, 72, 40, 3, 1, 0, 58, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 61, 4),
+    (2, 16, 16, 640, 320, 1, 1, 0, 60, 1),
+    (2, 16, 16, 128, 128, 3, 2, 0, 61, 1),
+    (2, 32, 32, 320, 72, 3, 1, 0, 62, 1),
+    (2, 8, 8, 128, 128, 3, 1, 1, 63, 3),
+    (4, 32, 32, 320, 640, 3, 1, 0, 63, 1),
     # 3-stage LDS-DMA ring (tiles 13..18): counted vmcnt + raw barrier; short and long K, split-K slices of 1-2 steps
     (2, 16, 16, 64, 64, 3, 1, 0, 13, 1),
     (2, 32, 32, 160, 320, 3, 1, 0, 14, 1),
@@ -291,7 +332,8 @@ def test_conv_plain(ops, cuda, case, both_splitk):
 
 @pytest.mark.parametrize("B,H,Cin,Cout,k,tile,split_k", [(4, 16, 2560, 1280, 1, 30, 3), (4, 16, 640, 1280, 3, 34, 4),
                                                          (4, 8, 1280, 640, 3, 40, 12), (4, 32, 320, 640, 3, 34, 2),
-                                                         (4, 32, 1920, 320, 3, 19, 8), (1, 24, 64, 200, 3, 12, 3)])
+                                                         (4, 32, 1920, 320, 3, 19, 8), (1, 24, 64, 200, 3, 12, 3),
+                                                         (4, 16, 1280, 1280, 1, 58, 3), (4, 8, 640, 1280, 3, 63, 6)])
 def test_splitk_in_kernel_matches_reduce_launch_bitwise_and_is_stable(ops, cuda, B, H, Cin, Cout, k, tile, split_k):
     """The in-kernel reduction re-reads every slab in slice order, so it must equal the reduce-launch form BIT FOR BIT
     whichever workgroup arrives last, on every one of many back-to-back launches (stale slab lines in a CU's L1 / another
@@ -347,6 +389,71 @@ def test_conv_workgroup_orders_agree(ops, cuda, case, order):
     assert torch.equal(auto, ref)
 
 
+@pytest.mark.parametrize("nbytes", [4, 64, 200, 65536 + 12, 3 << 20])
+@pytest.mark.parametrize("tile", [0, 9, 19, 34])
+def test_conv_next_weight_prefetch_changes_nothing(ops, cuda, nbytes, tile):
+    """AptpConvGemmParams.prefetch: the workgroups only touch [prefetch, prefetch + bytes) (sizes below one line, ragged, more lines
+    than threads); the result is bitwise the one without it and the touched buffer is unchanged"""
+    g = torch.Generator().manual_seed(11)
+    x = nhwc(_rand((2, 128, 16, 16), g).bfloat16()).to(cuda)
+    pw = ops.pack_weight(_rand((192, 128, 3, 3), g, 0.03), _rand((192,), g, 0.1), device=cuda)
+    nxt = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, generator=g).to(cuda)
+    keep = nxt.clone()
+    y0 = ops.conv_gemm(x, pw, tile=tile)
+    y1 = ops.conv_gemm(x, pw, tile=tile, prefetch=nxt)
+    assert torch.equal(y0, y1) and torch.equal(nxt, keep)
+
+
+@pytest.mark.parametrize("tile,split_k", [(0, 1), (9, 1), (18, 1), (19, 1), (34, 1), (34, 2), (38, 1), (42, 1), (50, 1), (56, 1),
+                                          (58, 1), (60, 2), (63, 1)])
+@pytest.mark.parametrize("Cout", [320, 200])
+def test_groupnorm_takes_the_producer_column_statistics(ops, cuda, tile, split_k, Cout):
+    """conv_gemm(colstats=True) leaves per-(row block, channel) sum / sum of squares of what it stored with the tensor
+    (AptpConvGemmParams.colstat_out); GroupNorm finds them and skips its statistics pass.  Same result as the
+    statistics pass over the stored bf16 tensor, to bf16 rounding of the statistics' inputs."""
+    g = torch.Generator().manual_seed(5 + tile)
+    B, H, W, Cin = 2, 32, 32, 136
+    x = nhwc(_rand((B, Cin, H, W), g).bfloat16()).to(cuda)
+    pw = ops.pack_weight(_rand((Cout, Cin, 3, 3), g, 0.05), _rand((Cout,), g, 0.3), device=cuda)
+    res = nhwc(_rand((B, Cout, H, W), g).bfloat16()).to(cuda)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(cuda), _rand((Cout,), g, 0.2).to(cuda)
+    y = ops.conv_gemm(x, pw, residual=res, colstats=True, tile=tile, split_k=split_k)
+    segs = ops._colstats_get(y, Cout)
+    assert segs is not None and len(segs) == 1
+    st, rpb, cseg = segs[0]
+    assert cseg == Cout and (H * W) % rpb == 0
+    nblk = B * H * W // rpb
+    want = y.float().reshape(nblk, rpb, Cout)
+    assert torch.allclose(st[:nblk, :, 0], want.sum(1), rtol=2e-2, atol=0.3)
+    assert torch.allclose(st[:nblk, :, 1], (want * want).sum(1), rtol=2e-2, atol=0.3)
+    with_stats = ops.groupnorm(y, gamma, beta, 8 if Cout == 200 else 32, 1e-5, True)
+    ops.COLSTATS = False
+    try:
+        plain = ops.groupnorm(y, gamma, beta, 8 if Cout == 200 else 32, 1e-5, True)
+    finally:
+        ops.COLSTATS = True
+    assert rel_l2(with_stats.float().cpu(), plain.float().cpu()) <= 3e-3
+    # overwriting the tensor without statistics forgets them
+    ops.conv_gemm(x, pw, out=y, tile=tile, split_k=split_k)
+    assert ops._colstats_get(y, Cout) is None
+
+
+@pytest.mark.parametrize("tile,split_k", [(0, 1), (9, 1), (19, 1), (34, 3), (25, 1), (50, 2), (56, 1), (59, 1), (63, 2)])
+@pytest.mark.parametrize("Cin2", [64, 200, 960])
+def test_conv_second_operand_segment(ops, cuda, tile, split_k, Cin2, both_splitk):
+    """x2: conv3x3(x) + conv1x1(x2) in one launch (the resnet's conv_shortcut as extra K-steps of conv2)"""
+    g = torch.Generator().manual_seed(17 + Cin2)
+    B, H, W, Cin, Cout = 2, 16, 16, 72, 136
+    x, x2 = _rand((B, Cin, H, W), g).bfloat16(), _rand((B, Cin2, H, W), g).bfloat16()
+    w = _rand((Cout, Cin, 3, 3), g, 1.0 / math.sqrt(9 * Cin)).bfloat16()
+    w2 = _rand((Cout, Cin2, 1, 1), g, 1.0 / math.sqrt(Cin2)).bfloat16()
+    b, b2 = _rand((Cout,), g, 0.1), _rand((Cout,), g, 0.1)
+    pw = ops.pack_weight_cat(ops.pack_weight(w.float(), b, device=cuda), w2.float(), b2)
+    y = ops.conv_gemm(nhwc(x).to(cuda), pw, x2=nhwc(x2).to(cuda), tile=tile, split_k=split_k)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1) + F.conv2d(x2.float(), w2.float(), b2)
+    assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), ref) <= REL_L2_TOL
+
+
 def test_conv_strided_views(ops, cuda, both_epilogues):
     """input is a channel slice of a wider buffer, output written into a slice of a wider buffer"""
     g = torch.Generator().manual_seed(7)
@@ -398,7 +505,7 @@ def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues, both_splitk):
     assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), ref) <= REL_L2_TOL
 
 
-@pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6), (1, 21), (2, 22), (1, 9), (1, 15)])
+@pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6), (1, 21), (2, 22), (1, 9), (1, 15), (1, 58), (2, 60), (1, 50)])
 def test_linear_geglu(ops, cuda, split_k, tile, both_epilogues, both_splitk):
     g = torch.Generator().manual_seed(13)
     B, L, C, inner = 2, 96, 64, 256
@@ -539,7 +646,8 @@ def test_layernorm(ops, cuda, rows, C):
 
 
 @pytest.mark.parametrize("rows,C,N,tile", [(96, 64, 64, 0), (200, 192, 320, 0), (2048, 128, 320, 9), (300, 640, 640, 21),
-                                            (128, 320, 320, 34), (130, 640, 1280, 38), (256, 1280, 1280, 42)])
+                                            (128, 320, 320, 34), (130, 640, 1280, 38), (256, 1280, 1280, 42),
+                                            (300, 640, 640, 58), (1024, 1280, 1280, 60)])
 def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile, both_epilogues):
     """the per-row (sum, sumsq) partials a producer GEMM emits (one slot per N-tile x wave column) add up to the
     statistics of the bf16 values it stored, for 4- and 8-wave tiles, ragged rows and a residual in the epilogue"""
@@ -576,7 +684,7 @@ def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile, both_epilogues
 @pytest.mark.parametrize("rows,C,N,tile,split_k,geglu", [(96, 64, 192, 0, 1, False), (200, 320, 384, 0, 1, False),
                                                          (2048, 320, 128, 18, 1, False), (256, 1280, 640, 25, 3, False),
                                                          (130, 640, 2560, 21, 1, True), (64, 1280, 5120, 40, 1, True),
-                                                         (300, 320, 1280, 9, 2, True)])
+                                                         (300, 320, 1280, 9, 2, True), (1024, 1280, 1920, 59, 1, False), (300, 640, 2560, 61, 2, True)])
 def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, geglu, both_epilogues, both_splitk):
     """linear(LayerNorm(x)) in one launch (gamma folded into the weights, mean / rstd from the producer's row
     statistics) against F.layer_norm + F.linear in fp32 on the same bf16 x: blocks.py:782-785,808-813,821-823,41-50"""

@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--tiles", type=str, default="", help="comma-separated APTP_TILE_* ids: only these are candidates (with --refine: a new tile against the committed table)")
     args = ap.parse_args()
     lib = ops._lib.load()
     if args.train:
@@ -161,7 +162,11 @@ def tune(args, lib, log):
         else:
             timer = lambda q: time_launch(lib, q)
         t_base = timer(base)
-        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18, 21, 22, 24, 25, 26, 27, 30, 31, 32, 35, 36, 38, 40] if p0.act == ACT_GEGLU else list(range(1, 45))
+        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18, 21, 22, 24, 25, 26, 27, 30, 31, 32, 35, 36, 38, 40] if p0.act == ACT_GEGLU else list(range(1, 64))
+        if p0.act == ACT_GEGLU:
+            tiles += [45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 57, 58, 59, 60, 61, 62, 63]
+        if args.tiles:
+            tiles = [int(v) for v in args.tiles.split(",") if int(v) in tiles]
         splits = [1, 2, 3, 4, 6, 8, 12, 16, 24]
         if args.quick:
             splits = [1, 2, 4, 8]

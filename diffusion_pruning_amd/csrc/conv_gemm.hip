@@ -19,11 +19,16 @@ __device__ unsigned long long g_stamps[4096 * 4];
 // barrier passed), [2] K loop done, [3] epilogue done and its stores drained
 __device__ unsigned long long g_phase[4096 * 4];
 #define APTP_PHASE(i) do { st_phase[i] = __builtin_readcyclecounter() - st_entry; } while (0)
+// epilogue timeline (absolute cycles): [0] entry, [1] stages free (barrier passed), [2] first fragment's per-column half in LDS,
+// [4] all stores issued, [5] stores drained
+__device__ unsigned long long g_epi[4096 * 8];
+#define APTP_EPI(k) do { if ((threadIdx.x & 63) == 0) g_epi[((blockIdx.x * 8 + (threadIdx.x >> 6)) & 4095) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #define APTP_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
     if ((i) > 0) st_acc[(i) - 1] += t_ - st_prev; st_prev = t_; } while (0)
 #else
 #define APTP_STAMP(i) do { } while (0)
 #define APTP_PHASE(i) do { } while (0)
+#define APTP_EPI(k) do { } while (0)
 #endif
 #ifndef APTP_ABLATE
 #define APTP_ABLATE 0   // timing experiments only (tools/ablate_conv.py): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no ds_read, 8 no barrier,
@@ -468,6 +473,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
     // (cross-lane exchange through LDS inside one wave: tell the compiler, see the column-statistics staging below)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (i == 0) APTP_EPI(2);
     // transposed domain: + residual, depth lerp, round, 16-byte store, row statistics
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -528,6 +534,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
       }
     }
   }
+  APTP_EPI(4);
   if constexpr (!GEGLU && WL >= 32) {
     if (p.cstat_out) {
       // GroupNorm statistics for the consumer of y: per channel, the sum / sum of squares over the WTM rows this wave
@@ -662,7 +669,9 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, f32x4 (&acc)[MF][
   constexpr int PITCH_MAX = WTN + 4;
   constexpr bool POW2 = ((WTN / 8) & (WTN / 8 - 1)) == 0;
   if (p.epi16 && (POW2 || !p.rstat_out)) {
+    APTP_EPI(0);
     __syncthreads();                        // every wave is done reading the operand stages
+    APTP_EPI(1);
     float* buf = reinterpret_cast<float*>(smem) + wave * 16 * PITCH_MAX;
     if (p.act == APTP_ACT_GEGLU) {
       if constexpr (NF % 2 == 0) tile_epilogue_lds<true, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, ln_mean, ln_rstd, buf);
@@ -1348,6 +1357,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
   run_epilogue<NW, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, cw, ln_mean, ln_rstd, smem);
 #ifdef APTP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  APTP_EPI(5);
   APTP_PHASE(3);
   if (lane == 0 && kz == 0) {
     const int slot = (blockIdx.x * NW + wave) & 4095;
@@ -1799,6 +1809,9 @@ void launch_tile_pp(const KParams& k, hipStream_t s) {
 #ifdef APTP_STAMPS
 extern "C" int aptp_debug_read_stamps(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int aptp_debug_read_epi(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_epi), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
 }
 extern "C" int aptp_debug_read_phases(unsigned long long* dst, int n_words) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);

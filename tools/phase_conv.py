@@ -39,3 +39,11 @@ for (M, Cin, Cout, tile, res) in cases:
     print(f"M{M} K{Cin} N{Cout} tile {tile} res {int(res)}: launch {us:5.1f} us | wave timeline (mean / max over {nw} waves, us): "
           f"prologue issued {m[0]:.2f}/{mx[0]:.2f}  first tile landed {m[1]:.2f}/{mx[1]:.2f}  loop done {m[2]:.2f}/{mx[2]:.2f}  "
           f"epilogue drained {m[3]:.2f}/{mx[3]:.2f}", flush=True)
+    eb = np.zeros(4096 * 8, dtype=np.uint64)
+    raw.aptp_debug_read_epi(eb.ctypes.data_as(ctypes.c_void_p), eb.size)
+    e = eb.reshape(4096, 8).astype(np.float64)
+    e = e[(e[:, 0] > 0) & (e[:, 5] > e[:, 0])]
+    d = (e[:, 1:6] - e[:, 0:1]) / (GHZ * 1e3)
+    dm = d.mean(0)
+    print(f"      epilogue (us since its entry, mean over {len(e)} waves): stages free {dm[0]:.2f}  first fragment in LDS {dm[1]:.2f}  "
+          f"[3 unused]  all stores issued {dm[3]:.2f}  drained {dm[4]:.2f}", flush=True)

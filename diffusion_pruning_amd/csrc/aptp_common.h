@@ -58,3 +58,21 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Next-launch weight prefetch (AptpConvGemmParams.prefetch / AptpGroupNormParams.prefetch): touch one dword per 64-byte line
+// of slice j of nper of the xcd-th eighth of [ptr, ptr + bytes) by LDS-DMA into a 256-byte scratch row (no VGPRs; results
+// discarded).  A workgroup with linear id L runs on XCD L % 8 (round-robin dispatch), and the weight-major workgroup order
+// of the next conv_gemm launch hands the rows of that eighth of a [N][K] weight matrix to the same XCD: the lines land
+// in the L2 that will be asked for them.
+__device__ __forceinline__ void aptp_prefetch_slice(const char* ptr, int64_t bytes, int xcd, int j, int nper, int tid, int nt,
+                                                    unsigned* scratch) {
+  const int lines = (int)(bytes >> 6);
+  const int x0 = (int)(((int64_t)lines * xcd) >> 3), x1 = (int)(((int64_t)lines * (xcd + 1)) >> 3);
+  const int per = ((x1 - x0) + nper - 1) / nper;
+  const int l0 = x0 + j * per;
+  const int l1 = l0 + per < x1 ? l0 + per : x1;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  for (int l = l0 + tid; l < l1; l += nt)
+    __builtin_amdgcn_global_load_lds((gptr)(ptr + (int64_t)l * 64), (lptr)scratch, 4, 0, 0);
+}

@@ -643,23 +643,21 @@ __device__ __forceinline__ bool splitk_combine(const KParams& p, f32x4 (&acc)[MF
 }
 
 // Cold-weight prefetch (LDS-DMA kernels).  Every weight is read once per forward and the forward's working set exceeds
-// the 256 MB Infinity Cache, so each launch starts on HBM-cold weights.  With pf_ptr set, every
-// workgroup touches its 1/gridDim slice of the NEXT launch's weights at kernel entry, one dword per 64-byte line.
-// Measured on the headline forward (APTP_PREFETCH=1): within box noise of not doing it (178.7 vs 178.1 steps/s), and 4 %
-// slower when issued after the epilogue, where the wave's end waits for the loads -- the cold cost is latency per
-// K-step, which a warmer memory-side cache does not shorten.  Off by default; kept for the next experiment.
+// the 256 MB Infinity Cache, so each launch starts on cold weights (4.7 ms of conv_gemm per forward
+// against 4.0 ms with warm weights).  With pf_ptr set, every workgroup touches its share of the NEXT launch's weights at
+// kernel entry, one dword per 64-byte line, XCD-aware (aptp_prefetch_slice).  Measured on the headline forward: +1.6 %
+// (186.3 vs 183.4 steps/s) for weights up to 12 MB -- what fits the eight 4 MB L2s next to the running launch's own
+// traffic; +0.5 % without the size cap; a slice that ignores the XCDs (lines land in the Infinity Cache and in random L2s)
+// was neutral, and issuing the touches after the epilogue, where the wave's end waits for them, cost 4 %.
 __device__ __forceinline__ void prefetch_next(const KParams& p, int tid, int nt, unsigned* scratch) {
   if (!p.pf_ptr) return;
   // LDS-DMA loads into a 256-byte scratch row: no VGPRs, nothing waits on them but the counted vmcnt of the main loop
-  // (in-order retirement: they were issued before the first operand stage)
-  const int64_t lines = p.pf_bytes >> 6;
-  const int64_t per = (lines + gridDim.x - 1) / gridDim.x;
-  const int64_t l0 = (int64_t)blockIdx.x * per;
-  const int64_t l1 = l0 + per < lines ? l0 + per : lines;
-  typedef const __attribute__((address_space(1))) void* gptr;
-  typedef __attribute__((address_space(3))) void* lptr;
-  for (int64_t l = l0 + tid; l < l1; l += nt)
-    __builtin_amdgcn_global_load_lds((gptr)(p.pf_ptr + l * 64), (lptr)scratch, 4, 0, 0);
+  // (in-order retirement: they were issued before the first operand stage).
+  // XCD-aware split: workgroup L runs on XCD L % 8 (round-robin dispatch, see decode_block) and touches lines of the
+  // (L % 8)-th eighth of the buffer -- the rows of a [N][K] weight matrix that the weight-major order of the next launch
+  // hands to the same XCD, so the lines land in the L2 that will be asked for them, not only in the Infinity Cache.
+  const int xcd = blockIdx.x & 7;
+  aptp_prefetch_slice(p.pf_ptr, p.pf_bytes, xcd, blockIdx.x >> 3, ((int)gridDim.x + 7 - xcd) >> 3, tid, nt, scratch);
 }
 
 // picks the epilogue form (wave-uniform): the coalesced one needs 16-byte aligned bf16 rows (p.epi16, set on the host)
@@ -1745,7 +1743,7 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
              "conv_gemm: folded LayerNorm needs ln_colsum [N], ln_slots > 0, ln_C > 0 and a 1x1 filter");
   k.counters = p->tile_counters;
   k.pf_ptr = ((uintptr_t)p->prefetch & 3) ? nullptr : (const char*)p->prefetch;   // dword loads
-  k.pf_bytes = k.pf_ptr ? p->prefetch_bytes : 0;
+  k.pf_bytes = k.pf_ptr ? (p->prefetch_bytes < (1ll << 36) ? p->prefetch_bytes : (1ll << 36)) : 0;   // (line index fits an int)
   k.cstat_out = p->colstat_out; k.cstat_ld = p->colstat_ld;
   k.epi16 = !p->out_f32 && p->ldy % 8 == 0 && ((uintptr_t)p->y % 16) == 0 && nout % 8 == 0 &&
             (!p->residual || (p->ldres % 8 == 0 && ((uintptr_t)p->residual % 16) == 0)) &&

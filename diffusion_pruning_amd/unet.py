@@ -1550,6 +1550,9 @@ class UNet2DConditionModelGated(nn.Module):
         misc = self._misc_packs(dev)
         bp = self._batched_packs(dev)
         out_dtype = sample.dtype
+        if "_pf_plan" not in self.__dict__:
+            self.__dict__["_pf_plan"] = ops._PrefetchPlan()     # per model: teacher / student forwards alternate
+        ops._prefetch_plan = self.__dict__["_pf_plan"]
         ops._prefetch_plan.begin()
 
         # 1. time (unet_2d_conditional.py:1497-1519): sinusoid [cos|sin] -> Linear -> SiLU -> Linear; the SiLU that

@@ -121,10 +121,11 @@ typedef struct {
   const void* x2;
   int64_t ldx2;
   int32_t Cin2, cin2_pad;
-  /* optional: [prefetch, prefetch + prefetch_bytes) = an operand of the NEXT launch (its packed weights).  Workgroups that
-   * have finished their tile touch it (one dword per 64-byte line, results discarded) so that it is on its way into the
-   * 256 MB Infinity Cache when the next launch starts: every weight of the U-Net is read once per forward and would
-   * otherwise be fetched HBM-cold. */
+  /* optional: [prefetch, prefetch + prefetch_bytes) = an operand of the NEXT launch (its packed weights).  The workgroups
+   * touch it at kernel entry (one dword per 64-byte line, results discarded), each XCD its eighth of the buffer -- the rows
+   * the weight-major order of the next launch gives that XCD -- so that the weights are in the right L2 when the next launch
+   * starts: every weight of the U-Net is read once per forward and would otherwise be fetched cold.  Pays for buffers that
+   * fit the L2s (<= ~12 MB); 4-byte aligned. */
   const void* prefetch;
   int64_t prefetch_bytes;
   int32_t epilogue;     /* 0 = auto (coalesced 16-byte stores through an LDS transpose when y / residual / depth_in rows are

@@ -1545,15 +1545,19 @@ class UNet2DConditionModelGated(nn.Module):
             raise NotImplementedError("only the arguments the APTP trainer/pipeline pass are supported")
         dev = sample.device
         B = sample.shape[0]
+        # launch-order plan of the next-launch weight prefetch (ops._PrefetchPlan): one per model -- teacher and student
+        # forwards alternate -- and per mode (a training forward is followed by its backward launches)
+        plans = self.__dict__.setdefault("_pf_plans", {})
+        mode = torch.is_grad_enabled()
+        if mode not in plans:
+            plans[mode] = ops._PrefetchPlan()
+        ops._prefetch_plan = plans[mode]
+        ops._prefetch_plan.begin()
         if torch.is_grad_enabled() and self.conv_in.weight.requires_grad:
             return self._forward_ft(sample, timestep, encoder_hidden_states, return_dict)
         misc = self._misc_packs(dev)
         bp = self._batched_packs(dev)
         out_dtype = sample.dtype
-        if "_pf_plan" not in self.__dict__:
-            self.__dict__["_pf_plan"] = ops._PrefetchPlan()     # per model: teacher / student forwards alternate
-        ops._prefetch_plan = self.__dict__["_pf_plan"]
-        ops._prefetch_plan.begin()
 
         # 1. time (unet_2d_conditional.py:1497-1519): sinusoid [cos|sin] -> Linear -> SiLU -> Linear; the SiLU that
         # every resnet applies to emb (blocks.py:335) is fused into linear_2's epilogue.

@@ -1,35 +1,193 @@
-"""Headline benchmark: masked SD-2.1 U-Net denoise steps per second on MI355X (BASELINE.json configs[1]).
+"""Headline benchmark: masked SD-2.1 U-Net denoise steps per second on MI355X (BASELINE.json configs[1]), plus the
+data-parallel pruning train step (configs[2]/[3]) behind ``--config train``.
 
-A "step" is one UNet2DConditionModelGated.forward on a [4,4,64,64] latent batch (512x512 images, bs=4), fixed 50 %
-channel mask, synthetic latents / text states / seeded random-init weights, inputs resident in HBM.
-The whole forward is captured once into a HIP graph and replayed; K replays are timed between
-barrier + torch.cuda.synchronize().  Multi-GPU = independent replicas (inference shards by prompt, no
-data-path collective): one process per GPU, MAX time over ranks, value = all ranks' steps / that time.
+``python bench.py --gpus N --steps K --warmup W``
+    N == 1 (or WORLD_SIZE already set by torchrun): this process is a rank.
+    N  > 1 and WORLD_SIZE unset: this process only LAUNCHES -- it starts
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``
+    as a child BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the child's code.
+    Rank 0 reports ``n_gpus`` as the result of a device all-reduce of ones, so the record proves RCCL saw N ranks.
 
-Prints ONE JSON line (see the task contract) with two extra objects:
-  roofline      MFMA roofline of the dominant kernel family (conv_gemm_kernel<*>, implicit-GEMM conv/linear): achieved =
-                algorithmic FLOPs of all its launches in one forward / their measured device time (HIP events around a
-                graph that replays exactly those launches), peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
-  cpu_baseline  the oracle (PyTorch CPU restatement, fp32) timed on this host's cores on a bounded sample.
+--config infer (default)
+    A "step" is one UNet2DConditionModelGated.forward on a [4,4,64,64] latent batch (512x512 images, bs=4), fixed 50 %
+    channel mask, synthetic latents / text states / seeded random-init weights, inputs resident in HBM.
+    The forward is captured once into a HIP graph and replayed; K replays are timed between barrier +
+    torch.cuda.synchronize().  Multi-GPU = independent replicas (inference shards by prompt, no data-path
+    collective): MAX time over ranks, value = all ranks' steps / that time.
+--config train
+    A "step" is one APTP pruning train step (Pruner.step, trainer.py:1092-1254, on a synthetic CC3M-shape batch of bs=4
+    per GPU): router, dense teacher forward, soft-masked student forward + backward to the 84 gate gradients (both
+    replayed from HIP graphs), losses, chain rule into the router, ONE fused all-gather (text embeddings + normalised
+    architecture vectors, trainer.py:1152-1154), the distributed Sinkhorn assignment (quantizer.py:284-291, fused into
+    one all-gather) and ONE flat all-reduce of the router gradients (the DDP exchange of trainer.py:922), AdamW.
+    Reports steps/s summed over ranks, per-GPU steps/s and the collectives' share of a step.
+
+Prints ONE JSON line (see the task contract) with extra objects:
+  roofline        MFMA roofline of the dominant kernel family (conv_gemm*: implicit-GEMM conv/linear): achieved =
+                  algorithmic FLOPs of all its launches in one forward / their measured device time (HIP events on the
+                  launch stream around a HIP graph that replays exactly those launches); peak = 2500 TFLOP/s dense bf16
+                  (MI355X_MICROARCH.md); peak_measured = what a plain 8192^3 bf16 GEMM reaches on THIS box (hipBLASLt via
+                  torch.matmul, and this repo's own kernel) and a 1 GiB device copy; per_tile = the same fraction for each
+                  kernel instantiation.
+  roofline_groupnorm  HBM roofline of the GroupNorm(+SiLU) family: algorithmic bytes (x read once + y written once) / time.
+  cpu_baseline    the oracle (PyTorch CPU restatement, fp32) timed on this host's cores on a bounded sample: median of 5
+                  steps of the headline workload (bs=4, masked) and of BASELINE configs[0] (bs=1, dense).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=("infer", "train"), default="infer")
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--dense", action="store_true", help="(infer) mask == 1 instead of the fixed 50 %% mask")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline legs (timing only)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --dryrun-cpu)")
+    ap.add_argument("--dryrun-cpu", action="store_true",
+                    help="TEST ONLY: run the launch / rendezvous / timing / reporting logic on CPU with the emulated ops of "
+                         "tests/ on a tiny model (gloo); the printed line is marked as not a measurement")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 50 if args.config == "infer" else 10
+    if args.warmup is None:
+        args.warmup = 5 if args.config == "infer" else 3
+    return args
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: no torch.cuda call, no HIP call, nothing but a child process
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv) -> int:
+    """Start N ranks under torchrun as a CHILD process (never exec: a process that has touched the GPU must not be
+    replaced, and this one has not touched it at all), relay rank 0's JSON line, return the child's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    got = False
+    for line in proc.stdout:
+        ok = False
+        if line.startswith("{"):
+            try:
+                ok = "metric" in json.loads(line)
+            except ValueError:
+                ok = False
+        if ok and not got:
+            got = True
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and not got:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        return 1
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# rank
+# ----------------------------------------------------------------------------------------------------------------------
+class Rank:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch with "
+                             f"--nproc-per-node {args.gpus} (or let bench.py launch the ranks itself)")
+        self.cpu = args.dryrun_cpu
+        if self.cpu:
+            self.dev = torch.device("cpu")
+        else:
+            self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.dev)
+        self.n_seen = 1
+        # APTP_BENCH_FORCE_DIST=1: bring the process group up even for one rank (exercises RCCL init / all-reduce /
+        # barrier on a one-GPU box)
+        self.dist = self.world > 1 or os.environ.get("APTP_BENCH_FORCE_DIST") == "1"
+        if self.dist:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = args.backend or ("gloo" if self.cpu else "nccl")
+            kw = {} if self.cpu else {"device_id": self.dev}
+            dist.init_process_group(backend=backend, **kw)
+            ones = torch.ones(1, device=self.dev)
+            dist.all_reduce(ones)                       # the record's n_gpus is what the collective library saw
+            self.n_seen = int(ones.item())
+            assert self.n_seen == self.world, (self.n_seen, self.world)
+
+    def sync(self):
+        if not self.cpu:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist:
+            self.torch.distributed.barrier()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if not self.dist:
+            return seconds
+        te = self.torch.tensor([seconds], device=self.dev, dtype=self.torch.float64)
+        self.torch.distributed.all_reduce(te, op=self.torch.distributed.ReduceOp.MAX)
+        return float(te.item())
+
+    def timed(self, run, steps, warmup):
+        """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(warmup):
+            run()
+        self.sync()
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        self.sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def finish(self):
+        if self.dist:
+            self.torch.distributed.destroy_process_group()
 
 
 def fixed_half_mask(structure, device):
     """every 32-wide gate keeps even entries, head gates keep the first floor(h/2) heads, all depth gates on"""
+    import torch
     width = []
     for sub in structure["width"]:
         for w in sub:
@@ -44,6 +202,7 @@ def fixed_half_mask(structure, device):
 
 
 def ones_mask(structure, device):
+    import torch
     return {"width": [torch.ones(1, w, device=device) for sub in structure["width"] for w in sub],
             "depth": [torch.ones(1, device=device) for sub in structure["depth"] for d in sub if d == 1]}
 
@@ -54,50 +213,42 @@ def algorithmic_flops(masked: bool, batch: int, latent: int) -> float:
     return 2.0 * (223.66507008e9 if masked else 402.12668416e9) * batch
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--latent", type=int, default=64)
-    ap.add_argument("--dense", action="store_true", help="mask == 1 instead of the fixed 50 %% mask")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    args = ap.parse_args()
+def _dryrun_install():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests import bench_dryrun
+    return bench_dryrun
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
+def run_infer(R: Rank):
+    torch, args, dev = R.torch, R.args, R.dev
     from diffusion_pruning_amd import ops
     from diffusion_pruning_amd.unet import UNet2DConditionModelGated
 
-    model = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
+    if R.cpu:
+        model_kw = _dryrun_install().install_infer()
+    else:
+        model_kw = {}
+    model = UNet2DConditionModelGated(**model_kw).init_synthetic(seed=0).to(dev)
     structure = model.get_structure()
     model.set_structure(ones_mask(structure, dev) if args.dense else fixed_half_mask(structure, dev))
 
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    g = torch.Generator(device="cpu").manual_seed(1234 + R.rank)
     B, L = args.batch, args.latent
+    xdim = model.config["cross_attention_dim"]
     sample = torch.randn(B, 4, L, L, generator=g).to(dev)
-    ehs = torch.randn(B, 77, 1024, generator=g).to(dev)
+    ehs = torch.randn(B, 77, xdim, generator=g).to(dev)
     t = torch.full((B,), 500, dtype=torch.int64, device=dev)
 
     def step():
         return model(sample, t, ehs, return_dict=False)[0]
 
+    roofline = roofline_gn = cpu_baseline = None
     with torch.no_grad():
         out = step()                      # builds the packed-weight plans
-        torch.cuda.synchronize()
+        R.sync()
         assert torch.isfinite(out).all()
-        if args.no_graph:
+        gout = None
+        if args.no_graph or R.cpu:
             run = step
         else:
             side = torch.cuda.Stream()
@@ -109,81 +260,133 @@ def main():
             with torch.cuda.graph(graph):
                 gout = step()
             run = graph.replay
-
-        def barrier():
-            if world > 1:
-                torch.distributed.barrier()
-
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if not args.no_graph:
+        elapsed = R.timed(run, args.steps, args.warmup)
+        if gout is not None:
             # the timed replays computed the same thing as the eager forward above (deterministic kernels, same inputs)
             d = float((gout.float() - out.float()).abs().max())
             assert torch.isfinite(gout).all() and d <= 1e-2 * float(out.float().abs().max()), f"graph replay differs from eager: {d}"
-        if world > 1:
-            te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(te.item())
-
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
-
-        roofline = None
-        cpu_baseline = None
-        if rank == 0:
+        value = R.world * args.steps / elapsed
+        if R.rank == 0 and not R.cpu and not args.no_extras:
             roofline = measure_roofline(ops, step, dev)
-            flops = algorithmic_flops(not args.dense, B, L)
-            roofline["whole_step_tflops"] = round(flops / (ms_per_step * 1e-3) / 1e12, 1)
-            if world == 1 and not args.no_cpu_baseline:
+            if L == 64:
+                flops = algorithmic_flops(not args.dense, B, L)
+                roofline["whole_step_tflops"] = round(flops / (ms_per_step * 1e-3) / 1e12, 1)
+            roofline["peak_measured"] = measure_peaks(ops, dev)
+            roofline_gn = measure_gn_roofline(ops, step, dev)
+            if R.world == 1 and not args.no_cpu_baseline:
                 cpu_baseline = measure_cpu_baseline(model, args.dense)
-
-    if rank == 0:
-        line = {
-            "metric": "denoise-steps/s (SD-2.1 U-Net forward, 512x512, bs=4 per GPU, 50% channel mask)" if not args.dense
-                      else "denoise-steps/s (SD-2.1 U-Net forward, 512x512, bs=4 per GPU, dense)",
-            "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: SD-2.1 UNet2DConditionModelGated.forward, 64x64 latents "
-                                   f"(512x512), bs={B}/GPU, " + ("mask=1" if args.dense else "fixed 50% mask (gated semantics)")
-                                   + ", seeded random-init weights, HIP graph replay",
-                       "global_batch": B * world, "parallelism": f"replicas x{world} (no data-path collective)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    if R.rank != 0:
+        return None
+    what = "mask=1" if args.dense else "fixed 50% mask (gated semantics)"
+    line = {
+        "metric": "denoise-steps/s (SD-2.1 U-Net forward, 512x512, bs=4 per GPU, " + ("dense)" if args.dense else "50% channel mask)"),
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": R.n_seen, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: SD-2.1 UNet2DConditionModelGated.forward, 64x64 latents "
+                               f"(512x512), bs={B}/GPU, {what}, seeded random-init weights, HIP graph replay",
+                   "global_batch": B * R.world, "parallelism": f"replicas x{R.world} (no data-path collective)"},
+        "per_gpu_steps_per_s": round(value / R.world, 3),
+        "roofline": roofline, "roofline_groupnorm": roofline_gn, "cpu_baseline": cpu_baseline,
+    }
+    return line
 
 
-def measure_roofline(ops, step, dev):
-    """Device time of every conv_gemm launch of one forward (the dominant kernel family), measured with HIP events on
-    the launch stream around a HIP graph that replays exactly those launches."""
-    lib = ops._lib.load()
-    ops.LAUNCH_LOG = []
-    step()
-    torch.cuda.synchronize()
-    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
-    stream = torch.cuda.Stream()
+def run_train(R: Rank):
+    """BASELINE configs[2] (N = 1) / configs[3] (N > 1): the APTP pruning train step, data-parallel."""
+    torch, args, dev = R.torch, R.args, R.dev
+    from diffusion_pruning_amd import dist_utils
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+    from diffusion_pruning_amd.train_step import GraphedPrunerStep, PrunerStep, synthetic_batch
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+
+    depth_order = [-1, -2, 0, 1, -3, -4, 2, 3, -5, -6, 4, 5, -7, 6]
+    if R.cpu:
+        unet, text_dim, n_e = _dryrun_install().install_train()
+        latent = 8
+    else:
+        unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
+        text_dim, n_e, latent = 768, 8, args.latent
+    (unet.real if R.cpu else unet).freeze()
+    st = unet.get_structure() if not R.cpu else unet.real.get_structure()
+    torch.manual_seed(0)                                   # identical router replicas on every rank
+    hn = HyperStructure(structure=st, input_dim=text_dim, wn_flag=False, linear_bias=True).to(dev)
+    qz = StructureVectorQuantizer(n_e=n_e, structure=st, temperature=0.4, base=3, depth_order=depth_order,
+                                  resource_aware_normalization=False, optimal_transport=True,
+                                  fused_sinkhorn_allreduce=True).to(dev)
+    hn.train(); qz.train()
+    graphed = not (args.no_graph or R.cpu)
+    step = (GraphedPrunerStep if graphed else PrunerStep)(unet, hn, qz)
+    step.count_macs(latent)
+    opt = torch.optim.AdamW(step.trainable_parameters(), lr=2e-4)
+    xdim = 1024 if not R.cpu else unet.real.config["cross_attention_dim"]
+    batch = synthetic_batch(args.batch, latent, dev, seed=1234 + R.rank, cross_dim=xdim, text_dim=text_dim)   # rank-local shard
+    if graphed:
+        step.capture(batch)
+    timer = dist_utils.CollectiveTimer()
+    out = {}
+
+    def run():
+        out["o"] = step.train_step(opt, batch, pretrain=R.cpu)
+
+    elapsed = R.timed(run, args.steps, args.warmup)
+    # collective share: a few more steps with the device-side stopwatch around every collective of the step
+    dist_utils.COLLECTIVE_TIMER = timer
+    n_probe = min(args.steps, 5)
+    for _ in range(n_probe):
+        run()
+    R.sync()
+    dist_utils.COLLECTIVE_TIMER = None
+    spans = {k: round(v / n_probe, 4) for k, v in timer.total_ms().items()}
+    coll_ms = sum(spans.values())
+    # replicas must have stayed bit-identical (same averaged gradient on every rank)
+    flat = torch.cat([p.detach().float().flatten() for p in step.trainable_parameters()])
+    if R.world > 1:
+        lo, hi = flat.clone(), flat.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "router replicas diverged across ranks"
+    assert torch.isfinite(flat).all()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = R.world * args.steps / elapsed
+    if R.rank != 0:
+        return None
+    o = out["o"]
+    mem = None if R.cpu else round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+    return {
+        "metric": "pruning-train-steps/s (APTP Pruner.step: router + dense teacher fwd + soft-masked student fwd/bwd, SD-2.1, "
+                  "64x64 latents, bs=4 per GPU; summed over data-parallel ranks)",
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": R.n_seen, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[3]" if R.world > 1 else "BASELINE configs[2]") +
+                               f": APTP pruning train step, synthetic CC3M-shape batch, bs={args.batch}/GPU, "
+                               + ("U-Net passes replayed from HIP graphs, router eager" if graphed else "eager"),
+                   "global_batch": args.batch * R.world,
+                   "parallelism": f"dp{R.world}: frozen U-Net replicas; per step 1 fused all-gather [B,768+1620], 1 all-gather of "
+                                  "Sinkhorn scores [B,8], 1 flat fp32 all-reduce of 1.26 M router gradients"},
+        "per_gpu_steps_per_s": round(value / R.world, 3), "global_steps_per_s": round(args.steps / elapsed, 3),
+        "samples_per_s": round(value * args.batch, 2),
+        "collectives": {"ms_per_step": round(coll_ms, 4), "share_of_step": round(coll_ms / ms_per_step, 5), "spans_ms": spans,
+                        "how": "HIP events on the launch stream around each collective, mean of %d steps" % n_probe},
+        "loss": float(o["loss"].detach()), "resource_ratio": float(o["resource_ratio"]), "max_mem_GiB": mem,
+        "replicas_identical_after_run": True,
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# measurement legs (rank 0, after the timed region)
+# ----------------------------------------------------------------------------------------------------------------------
+def _time_graph(torch, stream, fn, reps=10):
+    """device time (ms) of fn()'s launches: captured into a HIP graph on `stream`, replayed `reps` times between events"""
     with torch.cuda.stream(stream):
-        def replay_all():
-            s = torch.cuda.current_stream().cuda_stream
-            for rec in log:
-                rc = lib.aptp_conv_gemm(ctypes.byref(rec["params"]), s)
-                assert rc == 0
-        replay_all()
+        fn()
         stream.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
-            replay_all()
-        reps = 10
+            fn()
         graph.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -191,10 +394,40 @@ def measure_roofline(ops, step, dev):
             graph.replay()
         e1.record(stream)
         stream.synchronize()
-        total_ms = e0.elapsed_time(e1) / reps
+        return e0.elapsed_time(e1) / reps
+
+
+def measure_roofline(ops, step, dev):
+    """Device time of every conv_gemm launch of one forward (the dominant kernel family), measured with HIP events on
+    the launch stream around a HIP graph that replays exactly those launches; then the same per kernel instantiation."""
+    import torch
+    lib = ops._lib.load()
+    ops.LAUNCH_LOG = []
+    step()
+    torch.cuda.synchronize()
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    stream = torch.cuda.Stream()
+
+    def replayer(recs):
+        def fn():
+            s = torch.cuda.current_stream().cuda_stream
+            for rec in recs:
+                rc = lib.aptp_conv_gemm(ctypes.byref(rec["params"]), s)
+                assert rc == 0
+        return fn
+    total_ms = _time_graph(torch, stream, replayer(log))
     flops = sum(r["flops"] for r in log)
     n = len(log)
     achieved = flops / (total_ms * 1e-3) / 1e12
+    per_tile = {}
+    groups = {}
+    for r in log:
+        groups.setdefault(int(r["params"].tile), []).append(r)
+    for tile, recs in sorted(groups.items()):
+        ms = _time_graph(torch, stream, replayer(recs), reps=5)
+        fl = sum(r["flops"] for r in recs)
+        tf = fl / (ms * 1e-3) / 1e12
+        per_tile[str(tile)] = {"launches": len(recs), "ms": round(ms, 4), "tflops": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
     # HBM-side bytes per launch of this kernel family come from separate rocprofv3 --pmc passes over this same command
     # (FETCH_SIZE and WRITE_SIZE cannot share a pass; gfx950 FETCH_SIZE correction applied) committed under profiles/.
     traffic, traffic_src = None, None
@@ -208,37 +441,113 @@ def measure_roofline(ops, step, dev):
                            " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, bytes per launch)")
         except Exception:  # noqa: BLE001
             traffic = None
-    return {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<BM,BN,WM,WN,STAGES,PP> / conv_gemm_kernel (implicit-GEMM conv/linear, all tile instantiations)",
+    return {"bound": "mfma", "kernel": "conv_gemm family (implicit-GEMM conv/linear, all tile instantiations; per_tile keys = AptpTile ids of include/aptp_hip.h)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n, "avg_launch_us": round(total_ms * 1e3 / n, 2),
-            "family_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(flops / 1e9, 1)}
+            "family_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(flops / 1e9, 1), "per_tile": per_tile}
+
+
+def measure_gn_roofline(ops, step, dev):
+    """HBM roofline of the GroupNorm(+SiLU) launches of one forward: algorithmic bytes = x read once + y written once."""
+    import torch
+    lib = ops._lib.load()
+    ops.GN_LAUNCH_LOG = []
+    step()
+    torch.cuda.synchronize()
+    log, ops.GN_LAUNCH_LOG = ops.GN_LAUNCH_LOG, None
+    if not log:
+        return None
+    stream = torch.cuda.Stream()
+
+    def fn():
+        s = torch.cuda.current_stream().cuda_stream
+        for rec in log:
+            rc = lib.aptp_groupnorm(ctypes.byref(rec["params"]), s)
+            assert rc == 0
+    ms = _time_graph(torch, stream, fn)
+    nbytes = sum(r["bytes"] for r in log)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "aptp_groupnorm family (gn_group / gn_stats / gn_finalize* / gn_apply)", "achieved": round(gbs, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "calls_per_step": len(log), "family_ms_per_step": round(ms, 4), "algorithmic_MB_per_step": round(nbytes / 1e6, 1)}
+
+
+def measure_peaks(ops, dev):
+    """Denominators measured on this box: a plain 8192^3 bf16 GEMM through hipBLASLt (torch.matmul) and
+    through this repo's own kernel, and a 1 GiB device-to-device copy (read + write bytes / time)."""
+    import torch
+    n = 8192
+    a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+
+    def t(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    fl = 2.0 * n ** 3
+    lib_tf = fl / t(lambda: torch.matmul(a, b), 10) / 1e12
+    pw = ops.pack_weight(b.t().float().contiguous(), None, device=dev)
+    x = a.view(1, n, 1, n)
+    own_tf = fl / t(lambda: ops.conv_gemm(x, pw, pad=0), 10) / 1e12
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    gbs = 2.0 * src.numel() / t(lambda: dst.copy_(src), 10) / 1e9
+    return {"gemm_bf16_8192_hipblaslt_tflops": round(lib_tf, 1), "gemm_bf16_8192_own_kernel_tflops": round(own_tf, 1),
+            "stream_copy_1GiB_GBs": round(gbs, 1)}
 
 
 def measure_cpu_baseline(model, dense):
-    """The oracle (PyTorch CPU fp32 restatement of the reference's diffusers path) on this host: one denoise step at
-    bs=1 of the same workload (a quarter of the bs=4 batch), all host cores."""
+    """The oracle (PyTorch CPU fp32 restatement of the reference's diffusers path) on this host: median of 5 denoise steps
+    of the headline workload (bs=4) after one warm-up, and the same for BASELINE configs[0] (bs=1, dense)."""
+    import torch
     from oracle import unet_oracle as O
     cfg = O.SD21
     params = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    mask = O.ones_mask(cfg) if dense else O.fixed_half_mask(cfg)
-    gates = O.assign_gates(cfg, mask)
     # torch's CPU kernels stop scaling (and regress badly) far below the 256 hardware threads of the GPU host;
     # 32 threads is what the sample is timed with and what "cores" reports.
     cores = min(os.cpu_count() or 1, int(os.environ.get("APTP_CPU_THREADS", "32")))
     torch.set_num_threads(cores)
-    with torch.no_grad():
-        sample, t, ehs = O.synthetic_inputs(cfg, 1, 64)
-        O.unet_forward(params, cfg, sample, t, ehs, gates, "gated")            # warm-up (bs=1)
-        sample, t, ehs = O.synthetic_inputs(cfg, 4, 64)
-        reps = 2
-        t0 = time.perf_counter()
+
+    def med(mask, bs, reps=5):
+        gates = O.assign_gates(cfg, mask)
+        sample, t, ehs = O.synthetic_inputs(cfg, bs, 64)
+        O.unet_forward(params, cfg, sample, t, ehs, gates, "gated")            # warm-up
+        ts = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             O.unet_forward(params, cfg, sample, t, ehs, gates, "gated")
-        dt = (time.perf_counter() - t0) / reps
-    return {"value": round(1.0 / dt, 5), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} denoise steps at bs=4 (the full step of the workload) after a bs=1 warm-up, {dt:.2f} s/step, gated "
-                      f"semantics (dense compute + mask multiply, as the reference does), fp32, torch {torch.__version__} CPU, "
-                      f"{cores} threads"}
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), ts
+    with torch.no_grad():
+        dt1, ts1 = med(O.ones_mask(cfg), 1)
+        dt4, ts4 = med(O.ones_mask(cfg) if dense else O.fixed_half_mask(cfg), 4)
+    return {"value": round(1.0 / dt4, 5), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"median of 5 denoise steps at bs=4 (the full step of the headline workload) after one warm-up: {dt4:.2f} s/step "
+                      f"(runs {', '.join('%.2f' % v for v in ts4)}), gated semantics (dense compute + mask multiply, as the reference "
+                      f"does), fp32, torch {torch.__version__} CPU, {cores} threads",
+            "config0_bs1_dense": {"value": round(1.0 / dt1, 5), "unit": "steps/s", "s_per_step": round(dt1, 3),
+                                  "sample": "BASELINE configs[0]: bs=1 dense, median of 5 after one warm-up (runs "
+                                            + ", ".join("%.2f" % v for v in ts1) + ")"}}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    R = Rank(args)
+    line = run_train(R) if args.config == "train" else run_infer(R)
+    if line is not None:
+        if R.cpu:
+            line["data"] = "DRYRUN on CPU with emulated ops and a tiny model: exercises launch/rendezvous/reporting only, NOT a measurement"
+        print(json.dumps(line), flush=True)
+    R.finish()
 
 
 if __name__ == "__main__":

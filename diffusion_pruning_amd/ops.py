@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -204,6 +205,8 @@ TUNING = _load_tuning()
 # Optional launch recorder used by bench.py's roofline leg: when a list, every aptp_conv_gemm launch appends
 # {"params": ConvGemmParams, "flops": algorithmic FLOPs, "keep": tensors referenced by the params}.
 LAUNCH_LOG = None
+# Same for aptp_groupnorm calls (bench.py's HBM roofline leg): {"params", "bytes": x read once + y written once, "keep"}
+GN_LAUNCH_LOG = None
 
 # Split-K launches combine their K-slices inside the kernel (AptpConvGemmParams.tile_counters) instead of launching
 # splitk_reduce_kernel; False restores the two-launch form (A/B timing, tests of both forms)
@@ -212,20 +215,36 @@ _counters = {}
 _N_COUNTERS = 1 << 16
 
 
+_N_SLABS = 16
+_counters_lock = threading.Lock()
+
+
 def _tile_counters(device):
-    """zero-initialised arrival counters shared by every split-K launch on the device (each launch leaves them zero).
-    Never created while a stream is capturing (the fill would only run at replay): such a call gets None and uses the
-    separate reduce launch."""
-    # (per device, not per stream: the buffer must exist before a stream starts capturing, and graph capture runs on a
-    # stream of its own; forwards running CONCURRENTLY on several streams would need one buffer each)
+    """Zero-initialised arrival counters of the split-K launches issued on the CURRENT stream (every launch leaves them
+    zero).  One pool of _N_SLABS slabs per device, created on first use outside stream capture (a fill recorded into a
+    graph would only run at replay); each stream that launches split-K work is handed its own slab on first use -- a
+    host-side table lookup, legal during capture -- so forwards running concurrently on different streams never share
+    counters.  Returns None (= use the separate reduce launch) when the pool cannot be created yet or is exhausted."""
     key = device.index if device.index is not None else torch.cuda.current_device()
-    buf = _counters.get(key)
-    if buf is None:
+    pool = _counters.get(key)
+    if pool is None:
         if torch.cuda.is_current_stream_capturing():
             return None
-        buf = torch.zeros(_N_COUNTERS, dtype=torch.int32, device=device)
-        _counters[key] = buf
-    return buf
+        with _counters_lock:
+            pool = _counters.get(key)
+            if pool is None:
+                pool = {"buf": torch.zeros(_N_SLABS, _N_COUNTERS, dtype=torch.int32, device=device), "slab": {}}
+                _counters[key] = pool
+    sid = torch.cuda.current_stream().cuda_stream
+    i = pool["slab"].get(sid)
+    if i is None:
+        with _counters_lock:
+            i = pool["slab"].get(sid)
+            if i is None:
+                if len(pool["slab"]) >= _N_SLABS:
+                    return None
+                i = pool["slab"][sid] = len(pool["slab"])
+    return pool["buf"][i]
 
 
 # AptpGroupNormParams.variant used when the caller asks for "auto" (0).  0 = the library's own choice (small maps in one
@@ -333,7 +352,21 @@ class _PrefetchPlan:
         return nxt
 
 
-_prefetch_plan = _PrefetchPlan()          # the plan of the forward in progress (a model installs its own, see unet.py)
+# The plan of the forward in progress is per THREAD (a model installs its own at the top of forward(), see unet.py):
+# forwards issued from different host threads -- e.g. one per stream -- never see each other's launch order.
+_tls = threading.local()
+
+
+def set_prefetch_plan(plan: Optional[_PrefetchPlan]):
+    _tls.prefetch_plan = plan
+    if plan is not None:
+        plan.begin()
+
+
+def _current_prefetch_plan() -> Optional[_PrefetchPlan]:
+    return getattr(_tls, "prefetch_plan", None)
+
+
 # Next-launch weight prefetch (AptpConvGemmParams.prefetch): on for weights that fit the XCD L2s next to the running
 # launch's own traffic (<= 12 MB: +1.5 % on the headline forward; all sizes +0.5 %; off: APTP_PREFETCH=0)
 PREFETCH_WEIGHTS = os.environ.get("APTP_PREFETCH", "1") == "1"
@@ -348,7 +381,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
               out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0,
               rowstats: bool = False, ln=None, colstats: bool = False, x2: Optional[torch.Tensor] = None,
-              prefetch: Optional[torch.Tensor] = None):
+              prefetch=None):
     """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites.
     rowstats: also emit the per-row (sum, sumsq) partials of y a following folded LayerNorm needs; returns (y, stats)
     with stats fp32 [slots / 2, M, 4] (two (sum, sumsq) slots per element), or (y, None) when this launch is split along K (the caller then normalises with
@@ -415,8 +448,12 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.tile = tile
     p.order = order
     p.epilogue = EPILOGUE
-    if PREFETCH_WEIGHTS and prefetch is None:
-        prefetch = _prefetch_plan.step(pw.w)
+    if prefetch is False:             # the "weights" of this launch are a temporary (conv_wgrad): not part of any plan
+        prefetch = None
+    elif PREFETCH_WEIGHTS and prefetch is None:
+        plan = _current_prefetch_plan()
+        if plan is not None:
+            prefetch = plan.step(pw.w)
     if prefetch is not None:
         p.prefetch, p.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     p.split_k = 1
@@ -537,6 +574,8 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
     if cnt is not None:
         p.counters = cnt.data_ptr()
     _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
+    if GN_LAUNCH_LOG is not None:
+        GN_LAUNCH_LOG.append({"params": p, "bytes": 2.0 * B * H * W * (C + Cp), "keep": (x, out, gamma, beta, ws, segs, cnt)})
     return (out, ws) if keep_stats else out
 
 
@@ -826,5 +865,5 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     Np = round_up(N, 8)
     if Np != N:
         dyt = torch.nn.functional.pad(dyt, (0, 0, 0, Np - N))
-    out = conv_gemm(dyt.view(1, Np, 1, Mp), pw, pad=0, out_f32=True)            # [1, Np, 1, Kp] fp32
+    out = conv_gemm(dyt.view(1, Np, 1, Mp), pw, pad=0, out_f32=True, prefetch=False)            # [1, Np, 1, Kp] fp32
     return out.view(Np, Kp)[:N, :K].reshape(N, KH * KW, C)

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from .dist_utils import _span
 from .estimation_utils import sample_gumbel, gumbel_softmax_sample, hard_concrete, importance_gumbel_softmax_sample
 
 
@@ -206,12 +207,14 @@ class StructureVectorQuantizer(nn.Module):
         B, K = Q.shape[1] * world, Q.shape[0]
         total = torch.sum(Q)
         if distributed:
-            dist.all_reduce(total)
+            with _span("all_reduce(sinkhorn)"):
+                dist.all_reduce(total)
         Q /= total
         for _ in range(self.sinkhorn_iterations):
             rows = torch.sum(Q, dim=1, keepdim=True)
             if distributed:
-                dist.all_reduce(rows)
+                with _span("all_reduce(sinkhorn)"):
+                    dist.all_reduce(rows)
             Q /= rows
             Q /= K
             Q /= torch.sum(Q, dim=0, keepdim=True)
@@ -224,7 +227,8 @@ class StructureVectorQuantizer(nn.Module):
         """One all-gather of the local score block, then the global Sinkhorn computed redundantly on every rank."""
         world, rank = dist.get_world_size(), dist.get_rank()
         blocks = [torch.empty_like(out) for _ in range(world)]
-        dist.all_gather(blocks, out.contiguous())
+        with _span("all_gather(sinkhorn scores)"):
+            dist.all_gather(blocks, out.contiguous())
         full = self._sinkhorn(torch.cat(blocks, dim=0), distributed=False)
         n = out.shape[0]
         return full[rank * n:(rank + 1) * n]

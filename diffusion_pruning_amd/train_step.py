@@ -23,6 +23,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import dist_utils
+from .dist_utils import _rank, _span, _world
 from .losses import ContrastiveLoss, ResourceLoss, compute_snr
 
 
@@ -51,14 +53,6 @@ class NoiseSchedule:
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
 
 
-def _world():
-    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-
-
-def _rank():
-    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-
-
 def gather_with_local_grad(*tensors: torch.Tensor) -> List[torch.Tensor]:
     """trainer.py:1147-1162: all-gather [B_loc, d_i] tensors across ranks under no_grad, re-insert the local block so
     gradients flow to the local rows only.  The tensors are concatenated along dim 1 so the step issues ONE collective."""
@@ -68,12 +62,13 @@ def gather_with_local_grad(*tensors: torch.Tensor) -> List[torch.Tensor]:
     widths = [t.shape[1] for t in tensors]
     with torch.no_grad():
         flat = torch.cat([t.detach().float() for t in tensors], dim=1).contiguous()
-        gathered = [torch.empty_like(flat) for _ in range(world)]
-        dist.all_gather(gathered, flat)
+        gathered = torch.empty((world,) + tuple(flat.shape), dtype=flat.dtype, device=flat.device)
+        with _span("all_gather(text, arch)"):
+            dist.all_gather(list(gathered.unbind(0)), flat)      # (views of one buffer: no extra copy under RCCL)
     outs = []
     off = 0
     for t, w in zip(tensors, widths):
-        blocks = [g[:, off:off + w].to(t.dtype) for g in gathered]
+        blocks = [gathered[r, :, off:off + w].to(t.dtype) for r in range(world)]
         blocks[rank] = t
         outs.append(torch.cat(blocks, dim=0))
         off += w
@@ -81,19 +76,113 @@ def gather_with_local_grad(*tensors: torch.Tensor) -> List[torch.Tensor]:
 
 
 def allreduce_mean_grads(params) -> None:
-    """One flat all-reduce (mean) of all router gradients: the DDP exchange of Pruner."""
+    """One flat all-reduce (mean) of all router gradients: the DDP exchange of Pruner (1.26 M parameters,
+    ~5 MB, latency-bound, so ONE collective instead of DDP's buckets).  For the 866 M parameters of an expert use
+    BucketedGradReducer."""
     world = _world()
     if world == 1:
         return
     params = [p for p in params if p.requires_grad]
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
-    dist.all_reduce(flat)
+    with _span("all_reduce(router grads)"):
+        dist.all_reduce(flat)
     flat /= world
     off = 0
     for p in params:
         n = p.numel()
         p.grad = flat[off:off + n].view_as(p).to(p.dtype)
         off += n
+
+
+class BucketedGradReducer:
+    """Data-parallel gradient exchange for the expert fine-tune (accelerate's DDP around
+    trainer.py:1616): the 866 M parameter gradients are averaged in fixed-size buckets that are launched as soon as every
+    gradient of a bucket has been accumulated, so the collectives overlap the rest of the backward.
+
+    MI355X-first choices: buckets are sized for xGMI's per-link bound rings (default 64 MiB of payload: large enough to
+    reach link bandwidth, small enough that the last bucket's exposed tail is a few ms), carried in bf16 (half the bytes
+    on the 7 x 153 GB/s links; the fp32 master gradient receives the mean), and buckets follow REVERSE parameter
+    registration order, which is the order the backward produces them in.  Works on any backend (gloo in the CPU tests)."""
+
+    def __init__(self, params, bucket_bytes: int = 64 << 20, wire_dtype: torch.dtype = torch.bfloat16):
+        self.params = [p for p in params if p.requires_grad]
+        self.wire_dtype = wire_dtype
+        self.buckets: List[List[torch.nn.Parameter]] = []
+        esz = torch.empty((), dtype=wire_dtype).element_size()
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):
+            nb = p.numel() * esz
+            if cur and cur_bytes + nb > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._pending = [0] * len(self.buckets)
+        self._work: List = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.reset()
+
+    def reset(self):
+        self._pending = [len(b) for b in self.buckets]
+        self._work = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def _on_grad(self, p):
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._launch(i)
+
+    def _launch(self, i):
+        if _world() == 1:
+            return
+        ps = self.buckets[i]
+        n = sum(p.numel() for p in ps)
+        flat = self._flat[i]
+        if flat is None or flat.device != ps[0].device:
+            flat = self._flat[i] = torch.empty(n, dtype=self.wire_dtype, device=ps[0].device)
+        off = 0
+        for p in ps:
+            k = p.numel()
+            g = p.grad
+            if g is None:
+                flat[off:off + k].zero_()
+            else:
+                flat[off:off + k].copy_(g.reshape(-1))
+            off += k
+        self._work.append((i, dist.all_reduce(flat, async_op=True)))
+
+    def finish(self):
+        """Wait for every bucket, write the mean back into .grad (buckets whose parameters received no gradient this
+        step are exchanged here so that all ranks issue the same collectives)."""
+        world = _world()
+        if world == 1:
+            self.reset()
+            return
+        for i, left in enumerate(self._pending):
+            if left > 0:
+                self._launch(i)
+        inv = 1.0 / world
+        for i, work in self._work:
+            work.wait()
+            flat, off = self._flat[i], 0
+            for p in self.buckets[i]:
+                k = p.numel()
+                mean = flat[off:off + k].view_as(p)
+                if p.grad is None:
+                    p.grad = mean.to(p.dtype) * inv
+                else:
+                    p.grad.copy_(mean).mul_(inv)
+                off += k
+        self.reset()
 
 
 class PrunerStep:
@@ -395,11 +484,16 @@ class FineTunerStep:
     """Expert fine-tuning step (pdm/training/trainer.py:1683-1765, config 5): teacher = dense ungated U-Net under
     no_grad, student = physically pruned expert (UNet2DConditionModelPruned) with every parameter trainable;
     loss = w_d * minSNR-MSE + w_b * block-MSE + w_k * distill-MSE.  Experts never communicate ("one expert per GPU" =
-    independent processes, scripts/aptp/finetune.py:27-28); `allreduce_mean_grads` covers the optional data-parallel
-    case."""
+    independent processes, scripts/aptp/finetune.py:27-28); ``data_parallel=True`` covers the optional case of one
+    expert on several GPUs with BucketedGradReducer."""
 
-    def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None):
+    def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None,
+                 data_parallel: bool = False, bucket_bytes: int = 64 << 20):
         self.student, self.teacher = student, teacher
+        # data_parallel: ONE expert trained on several GPUs (SURVEY C2): bf16 gradient buckets all-reduced while the
+        # backward is still running; the default is the reference's "one expert per GPU", which never communicates
+        self.reducer = BucketedGradReducer([p for p in student.parameters() if p.requires_grad], bucket_bytes) \
+            if data_parallel else None
         self.cfg = cfg or FinetuneLossConfig()
         self.schedule = schedule or NoiseSchedule()
         self.acts_s: Dict[str, torch.Tensor] = {}
@@ -447,7 +541,10 @@ class FineTunerStep:
         optimizer.zero_grad(set_to_none=True)
         out = self.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"], batch["target"])
         out["loss"].backward()
-        allreduce_mean_grads([p for p in self.student.parameters() if p.requires_grad])
+        if self.reducer is not None:
+            self.reducer.finish()
         optimizer.step()
-        self.student.invalidate_plans()       # the bf16 packs are rebuilt from the updated fp32 masters
+        # the bf16 packs follow the fp32 masters through the parameters' version counters (unet._PlanCache): the next
+        # forward re-packs what the optimizer changed; dropping the old packs now only returns their memory earlier
+        self.student.invalidate_plans()
         return out

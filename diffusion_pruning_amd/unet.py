@@ -130,6 +130,60 @@ def _take_dst(mod, B: int, H: int, W: int, C: int, device) -> Optional[torch.Ten
     return d[0].view(d[1], B, H, W, C, device)
 
 
+def _capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _versions(mod: nn.Module) -> tuple:
+    """in-place update counters of a module's parameters: optimizer steps, ``param.data.copy_`` and ``load_state_dict``
+    all bump them, so packs made from older values can be recognised as stale without any hook on the training loop"""
+    ps = mod.__dict__.get("_vparams")
+    if ps is None:
+        ps = mod.__dict__["_vparams"] = list(mod.parameters())      # (dropped by invalidate(): .to() may replace parameters)
+    return tuple(p._version for p in ps)
+
+
+class _PlanCache:
+    """Packed-weight plans of one module, keyed by (mask, semantics, device).
+
+    * At most ``cap`` UNPINNED entries; the oldest is evicted.  A plan that is created or looked up while a stream is
+      capturing is PINNED: a HIP graph bakes raw pointers to its packs, so it must outlive the graph and is only released
+      by ``clear()`` (``invalidate_plans``), however many other masks pass through the module in between.
+    * Every entry remembers the parameter versions it was packed from.  A lookup with newer versions is a miss and drops
+      the stale entry (a pinned one is parked, never returned again, so the memory a graph points to stays allocated):
+      fine-tuning forwards always compute with the current weights, whatever loop drives the optimizer."""
+
+    def __init__(self, cap: int = 4):
+        self.cap, self.entries, self.parked = cap, {}, []
+
+    def get(self, key, version):
+        e = self.entries.get(key)
+        if e is None:
+            return None
+        if e[0] != version:
+            del self.entries[key]
+            if e[2]:
+                self.parked.append(e[1])
+            return None
+        if not e[2] and _capturing():
+            e[2] = True
+        return e[1]
+
+    def put(self, key, version, plan):
+        unpinned = [k for k, e in self.entries.items() if not e[2]]
+        if len(unpinned) >= self.cap:
+            del self.entries[unpinned[0]]
+        self.entries[key] = [version, plan, _capturing()]
+        return plan
+
+    def clear(self):
+        self.entries.clear()
+        self.parked.clear()
+
+    def __len__(self):
+        return len(self.entries)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # ResNet blocks
 # ----------------------------------------------------------------------------------------------------------------
@@ -156,7 +210,7 @@ class ResnetBlock2DWidthGated(nn.Module):
         self.pruned = False
         self.dropped = False
         self.semantics = "gated"
-        self._plans: Dict[Any, dict] = {}
+        self._plans = _PlanCache()
 
     # ---- structure plumbing (blocks.py:373-382) -----------------------------------------------------------------
     def get_gate_structure(self):
@@ -174,6 +228,7 @@ class ResnetBlock2DWidthGated(nn.Module):
 
     def invalidate(self):
         self._plans.clear()
+        self.__dict__.pop("_vparams", None)
 
     # ---- execution plan -----------------------------------------------------------------------------------------
     def _mask_key(self):
@@ -184,11 +239,10 @@ class ResnetBlock2DWidthGated(nn.Module):
         """Packed (and, for a hard batch-shared mask, compacted) weights for the current gate value.
         force_dense: ignore the mask (full weights) — the autograd path needs the gate as an explicit multiply."""
         key = (None if force_dense else self._mask_key(), self.semantics, str(device))
-        pl = self._plans.get(key)
+        version = _versions(self)
+        pl = self._plans.get(key, version)
         if pl is not None:
             return pl
-        if len(self._plans) >= 4:
-            self._plans.pop(next(iter(self._plans)))
         mask = None if force_dense else self.gate.hard_uniform()
         cg = self.out_channels // self.groups
         pl = {"compact": mask is not None and not bool((mask == 1).all())}
@@ -232,8 +286,7 @@ class ResnetBlock2DWidthGated(nn.Module):
                 for cc in range(3):
                     corr[0, rc * 3 + cc] = T[:, list(valid[rc])][:, :, list(valid[cc])].sum(dim=(1, 2))
             pl["corr"] = corr.contiguous()
-        self._plans[key] = pl
-        return pl
+        return self._plans.put(key, version, pl)
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def _depth_state(self):
@@ -500,7 +553,7 @@ class Transformer2DModelWidthGated(nn.Module):
         self.prunable_macs, self.total_macs = 0.0, 0.0
         self.pruned = False
         self.dropped = False
-        self._plans: Dict[Any, dict] = {}
+        self._plans = _PlanCache()
 
     # ---- structure plumbing (blocks.py:1007-1022, 1357-1371) ------------------------------------------------------
     def get_gate_structure(self):
@@ -518,6 +571,7 @@ class Transformer2DModelWidthGated(nn.Module):
 
     def invalidate(self):
         self._plans.clear()
+        self.__dict__.pop("_vparams", None)
 
     # ---- execution plan -------------------------------------------------------------------------------------------
     def _keys(self):
@@ -530,11 +584,10 @@ class Transformer2DModelWidthGated(nn.Module):
 
     def plan(self, device, force_dense: bool = False) -> dict:
         key = ((None, None, None) if force_dense else self._keys(), str(device))
-        pl = self._plans.get(key)
+        version = _versions(self)
+        pl = self._plans.get(key, version)
         if pl is not None:
             return pl
-        if len(self._plans) >= 4:
-            self._plans.pop(next(iter(self._plans)))
         tb = self.transformer_blocks[0]
         dev = device
         pl = {}
@@ -583,8 +636,7 @@ class Transformer2DModelWidthGated(nn.Module):
         inner_pad = pl["ff1"].N // 2
         pl["ff2"] = ops.pack_weight(lin2.weight.detach(), lin2.bias.detach(), in_idx=live, cin_pad_to=16, device=dev)
         assert pl["ff2"].Cin == inner_pad, (pl["ff2"].Cin, inner_pad)
-        self._plans[key] = pl
-        return pl
+        return self._plans.put(key, version, pl)
 
     def _depth_state(self):
         return None, None
@@ -874,18 +926,24 @@ class Downsample2D(nn.Module):
     def __init__(self, channels: int):
         super().__init__()
         self.conv = Conv2dP(channels, channels, 3)
-        self._pw = None
+        self._pw, self._pw_ver, self._pinned, self._parked = None, None, False, []
 
     def invalidate(self):
-        self._pw = None
+        self._pw, self._pinned = None, False
+        self._parked.clear()
+        self.__dict__.pop("_vparams", None)
 
     def forward(self, hidden_states, scale: float = 1.0):
         x = _nhwc(hidden_states)
         if torch.is_grad_enabled():
             self.__dict__.pop("_out_dst", None)
-        if self._pw is None or self._pw.w.device != x.device:
+        ver = _versions(self)
+        if self._pw is None or self._pw.w.device != x.device or self._pw_ver != ver:
+            if self._pw is not None and self._pinned:
+                self._parked.append((self._pw, getattr(self, "_pwb", None)))      # a captured graph still points to it
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
-            self._pwb = None
+            self._pwb, self._pw_ver, self._pinned = None, ver, False
+        self._pinned = self._pinned or _capturing()
         if torch.is_grad_enabled() and self.conv.weight.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv_w(x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), stride=2, pad=1))
@@ -910,18 +968,24 @@ class Upsample2D(nn.Module):
     def __init__(self, channels: int):
         super().__init__()
         self.conv = Conv2dP(channels, channels, 3)
-        self._pw = None
+        self._pw, self._pw_ver, self._pinned, self._parked = None, None, False, []
 
     def invalidate(self):
-        self._pw = None
+        self._pw, self._pinned = None, False
+        self._parked.clear()
+        self.__dict__.pop("_vparams", None)
 
     def forward(self, hidden_states, output_size=None, scale: float = 1.0):
         x = _nhwc(hidden_states)
         if torch.is_grad_enabled():
             self.__dict__.pop("_out_dst", None)
-        if self._pw is None or self._pw.w.device != x.device:
+        ver = _versions(self)
+        if self._pw is None or self._pw.w.device != x.device or self._pw_ver != ver:
+            if self._pw is not None and self._pinned:
+                self._parked.append((self._pw, getattr(self, "_pwb", None)))      # a captured graph still points to it
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
-            self._pwb = None
+            self._pwb, self._pw_ver, self._pinned = None, ver, False
+        self._pinned = self._pinned or _capturing()
         if torch.is_grad_enabled() and self.conv.weight.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv_w(x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), ups=1))
@@ -1198,7 +1262,8 @@ class UNet2DConditionModelGated(nn.Module):
         self.resource_info_dict = None
         self.semantics = "gated"
         self._misc = None       # packed conv_in / time MLP / conv_out
-        self._batched = {}      # structure-key -> batched temb / ctx-kv packs
+        self._misc_parked = []  # superseded _misc packs a captured graph may still point to
+        self._batched = _PlanCache()      # structure-key -> batched temb / ctx-kv packs
 
     # ---- construction helpers -------------------------------------------------------------------------------------
     @classmethod
@@ -1229,7 +1294,8 @@ class UNet2DConditionModelGated(nn.Module):
     def invalidate_plans(self):
         """Drop every packed-weight cache (call after changing parameters)."""
         self._misc = None
-        self._batched = {}
+        self._misc_parked = []
+        self._batched.clear()
         for m in self.modules():
             if m is not self and hasattr(m, "invalidate"):
                 m.invalidate()
@@ -1363,9 +1429,15 @@ class UNet2DConditionModelGated(nn.Module):
         return [m for m in self.modules() if isinstance(m, Transformer2DModelWidthGated)]
 
     def _misc_packs(self, dev):
-        if self._misc is None or self._misc["dev"] != str(dev):
+        ver = tuple(p._version for mod in (self.conv_in, self.time_embedding, self.conv_norm_out, self.conv_out)
+                    for p in mod.parameters())
+        if self._misc is not None and self._misc["dev"] == str(dev) and self._misc["ver"] == ver:
+            self._misc["pinned"] = self._misc["pinned"] or _capturing()
+        if self._misc is None or self._misc["dev"] != str(dev) or self._misc["ver"] != ver:
+            if self._misc is not None and self._misc["pinned"]:
+                self._misc_parked.append(self._misc)
             cin_pad = ops.round_up(self.in_channels, 8)
-            m = {"dev": str(dev), "cin_pad": cin_pad}
+            m = {"dev": str(dev), "cin_pad": cin_pad, "ver": ver, "pinned": _capturing()}
             m["conv_in"] = ops.pack_weight(self.conv_in.weight.detach(), self.conv_in.bias.detach(), device=dev)
             te = self.time_embedding
             m["t1"] = ops.pack_weight(te.linear_1.weight.detach(), te.linear_1.bias.detach(), device=dev)
@@ -1387,12 +1459,10 @@ class UNet2DConditionModelGated(nn.Module):
         live_tr = [t for t in trans if not (t.depth_gated and (t.dropped or t._depth_state()[0] == 0.0))]
         tplans = [t.plan(dev) for t in live_tr]
         key = (tuple(id(p) for p in rplans), tuple(id(p) for p in tplans), str(dev))
-        bp = self._batched.get(key)
+        bp = self._batched.get(key, ())
         if bp is not None:
             return bp
-        if len(self._batched) >= 4:
-            self._batched.pop(next(iter(self._batched)))
-        bp = {"key": key}
+        bp = {"key": key, "plans": (rplans, tplans)}      # (the plans stay alive as long as their ids are a cache key)
         ws, bs, slots, off = [], [], [], 0
         for r, pl in zip(live_res, rplans):
             npad = pl["c_pad"]
@@ -1416,8 +1486,7 @@ class UNet2DConditionModelGated(nn.Module):
             bp["kv_pw"] = ops.pack_weight(torch.cat(ws, 0), None, device=dev)
         bp["kv_slots"] = slots
         bp["kv_gates"] = gates
-        self._batched[key] = bp
-        return bp
+        return self._batched.put(key, (), bp)
 
     def _project_context(self, encoder_hidden_states, bp, dev) -> CtxBundle:
         ehs = encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous()
@@ -1546,13 +1615,20 @@ class UNet2DConditionModelGated(nn.Module):
         dev = sample.device
         B = sample.shape[0]
         # launch-order plan of the next-launch weight prefetch (ops._PrefetchPlan): one per model -- teacher and student
-        # forwards alternate -- and per mode (a training forward is followed by its backward launches)
+        # forwards alternate -- and per mode; installed for THIS thread for the duration of the forward only
         plans = self.__dict__.setdefault("_pf_plans", {})
         mode = torch.is_grad_enabled()
         if mode not in plans:
             plans[mode] = ops._PrefetchPlan()
-        ops._prefetch_plan = plans[mode]
-        ops._prefetch_plan.begin()
+        ops.set_prefetch_plan(plans[mode])
+        try:
+            return self._forward_impl(sample, timestep, encoder_hidden_states, return_dict)
+        finally:
+            ops.set_prefetch_plan(None)
+
+    def _forward_impl(self, sample, timestep, encoder_hidden_states, return_dict):
+        dev = sample.device
+        B = sample.shape[0]
         if torch.is_grad_enabled() and self.conv_in.weight.requires_grad:
             return self._forward_ft(sample, timestep, encoder_hidden_states, return_dict)
         misc = self._misc_packs(dev)

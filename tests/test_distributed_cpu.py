@@ -178,3 +178,43 @@ def test_data_parallel_pruner_step_keeps_replicas_in_sync():
     assert torch.isfinite(res[0]["params"]).all()
     assert torch.equal(res[0]["params"], res[1]["params"])    # same averaged gradient applied on both ranks
     assert res[0]["loss"] != res[1]["loss"]                   # different data shards
+
+
+def _bucket_worker(rank, world):
+    """BucketedGradReducer: buckets in reverse registration order, launched from post-accumulate hooks,
+    mean written back into .grad; a parameter that received no gradient still takes part (zeros)."""
+    from diffusion_pruning_amd.train_step import BucketedGradReducer
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 16), nn.Linear(16, 4))
+    unused = nn.Parameter(torch.ones(5))
+    params = list(net.parameters()) + [unused]
+    red = BucketedGradReducer(params, bucket_bytes=300, wire_dtype=torch.float32)      # several small buckets
+    nb = len(red.buckets)
+    x = torch.full((2, 8), float(rank + 1))
+    net(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    red.finish()
+    out = {"nb": nb, "unused": unused.grad.clone()}
+    for i, (p, g) in enumerate(zip(net.parameters(), local)):
+        out[f"g{i}"] = p.grad.clone()
+        out[f"l{i}"] = g
+    # second step through the same reducer (buffers reused, counters reset)
+    for p in params:
+        p.grad = None
+    net(x * 2).sum().backward()
+    red.finish()
+    out["g0_step2"] = net[0].weight.grad.clone()
+    out["l0_step2_scale"] = 2.0
+    return out
+
+
+def test_bucketed_grad_reducer_means_gradients_across_ranks():
+    res = _run(_bucket_worker)
+    assert res[0]["nb"] >= 3
+    n = sum(1 for k in res[0] if k.startswith("g") and k[1:].isdigit())
+    for i in range(n):
+        mean = (res[0][f"l{i}"] + res[1][f"l{i}"]) / 2
+        for r in (0, 1):
+            assert torch.allclose(res[r][f"g{i}"], mean, atol=1e-6), i
+    assert torch.equal(res[0]["unused"], torch.zeros(5))
+    assert torch.equal(res[0]["g0_step2"], res[1]["g0_step2"])

@@ -206,3 +206,68 @@ def test_vectorised_relaxation_equals_the_per_segment_loop():
     (out * wgt).sum().backward()
     (ref2 * wgt).sum().backward()
     assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)    # the depth columns sum many products: order of summation only
+
+
+def test_plan_cache_pins_plans_seen_during_capture_and_drops_stale_ones(monkeypatch):
+    """a captured HIP graph bakes pointers to a plan's packs, so a plan created or used during capture must
+    survive any number of other masks; and packs made from older parameter values must never be served again."""
+    from diffusion_pruning_amd import unet as U
+    c = U._PlanCache(cap=4)
+    capturing = {"on": False}
+    monkeypatch.setattr(U, "_capturing", lambda: capturing["on"])
+    c.put("m0", (0,), "plan0")
+    capturing["on"] = True
+    assert c.get("m0", (0,)) == "plan0"             # used while capturing -> pinned
+    c.put("mcap", (0,), "plancap")                  # created while capturing -> pinned
+    capturing["on"] = False
+    for i in range(1, 9):                           # eight more masks pass through a cache of four
+        c.put(f"m{i}", (0,), f"plan{i}")
+    assert c.get("m0", (0,)) == "plan0" and c.get("mcap", (0,)) == "plancap"
+    assert c.get("m1", (0,)) is None and c.get("m8", (0,)) == "plan8"
+    assert sum(1 for e in c.entries.values() if not e[2]) <= 4
+    # an in-place parameter update bumps the version: stale entries are misses; a pinned one stays allocated (parked)
+    assert c.get("m8", (1,)) is None and "m8" not in c.entries
+    assert c.get("m0", (1,)) is None and "plan0" in c.parked
+    c.clear()
+    assert len(c) == 0 and not c.parked
+
+
+def test_resnet_plan_follows_in_place_parameter_updates(tiny):
+    """a fine-tuning loop that never calls invalidate_plans() must still compute with the current weights"""
+    cfg, model, params = tiny
+    model.set_structure(clone_mask(O.fixed_half_mask(cfg)))
+    r = model.down_blocks[0].resnets[0]
+    p0 = r.plan(torch.device("cpu"))
+    assert r.plan(torch.device("cpu")) is p0
+    with torch.no_grad():
+        r.conv1.weight.mul_(2.0)                    # what optimizer.step() does: an in-place update
+    p1 = r.plan(torch.device("cpu"))
+    assert p1 is not p0
+    assert torch.allclose(p1["w1"].w.float(), (p0["w1"].w.float() * 2), rtol=1e-2)
+    assert len(r._plans) == 1                       # the stale plan is gone, not merely shadowed
+    t = model.down_blocks[0].attentions[0]
+    q0 = t.plan(torch.device("cpu"))
+    with torch.no_grad():
+        t.proj_in.bias.add_(1.0)
+    assert t.plan(torch.device("cpu")) is not q0
+
+
+def test_prefetch_plan_is_per_thread_and_scoped_to_the_forward(tiny):
+    import threading
+    from diffusion_pruning_amd import ops
+    cfg, model, params = tiny
+    seen = {}
+
+    def probe(x, pw, **kw):
+        seen.setdefault(threading.get_ident(), []).append(ops._current_prefetch_plan())
+        return hip_emulator.conv_gemm(x, pw, **kw)
+    ops.conv_gemm = probe                           # (restored by the fixture's monkeypatch teardown)
+    sample, t, ehs = O.synthetic_inputs(cfg, 1, 16)
+    run(model, O.ones_mask(cfg), sample, t, ehs)
+    main_plans = set(id(p) for p in seen[threading.get_ident()])
+    assert len(main_plans) == 1 and None not in seen[threading.get_ident()]
+    assert ops._current_prefetch_plan() is None     # cleared when the forward returns
+    other = {}
+    th = threading.Thread(target=lambda: other.setdefault("plan", ops._current_prefetch_plan()))
+    th.start(); th.join()
+    assert other["plan"] is None                    # another thread never sees this thread's plan

@@ -113,13 +113,25 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return _bf(F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps))
 
 
-def attention(q, k, v, heads, scale=None, out=None):
+def attention(q, k, v, heads, scale=None, out=None, lse=None):
+    """same rounding points as attn_fwd_kernel: scores and the softmax denominator in fp32, the un-normalised probabilities
+    rounded to bf16 before P.V (bf16 rounding is relative, so rounding against the final row maximum instead of the
+    kernel's running maximum differs only at fp32 level), output rounded to bf16"""
     B, Lq, _ = q.shape
     Lk = k.shape[1]
+    sc = (1.0 / 8.0) if scale is None else scale
 
     def hd(t, L):
         return t.float().reshape(B, L, heads, 64).transpose(1, 2)
-    o = F.scaled_dot_product_attention(hd(q, Lq), hd(k, Lk), hd(v, Lk))
+    qh, kh, vh = hd(q, Lq), hd(k, Lk), hd(v, Lk)
+    o = torch.empty(B, heads, Lq, 64)
+    step = max(1, (1 << 24) // max(1, Lk))               # bound the [rows, Lk] score block (L = 4096 at SD-2.1 level 0)
+    for b in range(B):
+        for h in range(heads):
+            for r0 in range(0, Lq, step):
+                s_ = (qh[b, h, r0:r0 + step] @ kh[b, h].t()) * sc
+                p = torch.exp(s_ - s_.max(dim=1, keepdim=True)[0])
+                o[b, h, r0:r0 + step] = (_bf(p).float() @ vh[b, h]) / p.sum(dim=1, keepdim=True)
     return _bf(o.transpose(1, 2).reshape(B, Lq, heads * 64))
 
 

@@ -6,6 +6,7 @@ import torch
 from oracle import unet_oracle as O
 
 pytestmark = pytest.mark.gpu
+from tests.margins import check  # noqa: E402
 
 
 def rel_l2(a, b):
@@ -34,7 +35,7 @@ def test_parameter_gradients_match_oracle(cuda, seed, keep, ndoff):
     out_ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, {k: [v.clone() for v in vs] for k, vs in mask.items()}), "pruned")
     (out_ref * R).sum().backward()
     out = pm(sample.to(cuda), t.to(cuda), ehs.to(cuda)).sample
-    assert rel_l2(out.detach().float().cpu(), out_ref.detach()) <= 2e-2
+    check(rel_l2(out.detach().float().cpu(), out_ref.detach()), 2e-2, "forward")
     (out.float() * R.to(cuda)).sum().backward()
     torch.cuda.synchronize()
     errs = {}
@@ -61,9 +62,9 @@ def test_parameter_gradients_match_oracle(cuda, seed, keep, ndoff):
     e_all = rel_l2(torch.cat(got_all), torch.cat(ref_all))
     med = sorted(errs.values())[len(errs) // 2]
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert e_all <= 6e-2, (e_all, worst)
-    assert med <= 6e-2, (med, worst)
-    assert worst[0][1] <= 0.25, worst
+    check(e_all, 6e-2, "all parameter gradients")
+    check(med, 6e-2, "median parameter")
+    check(worst[0][1], 0.25, "worst parameter " + worst[0][0])
 
 
 def test_finetune_step_updates_only_live_parameters(cuda):

@@ -7,6 +7,7 @@ import torch
 from oracle import unet_oracle as O
 
 pytestmark = pytest.mark.gpu
+from tests.margins import check  # noqa: E402
 
 
 def rel_l2(a, b):
@@ -32,7 +33,7 @@ def test_config0_dense_bs1(sd21, cuda):
         model.set_structure({k: [v.to(cuda) for v in vs] for k, vs in O.ones_mask(cfg).items()})
         out = model(sample.to(cuda), t.to(cuda), ehs.to(cuda)).sample.float().cpu()
     e = rel_l2(out, ref)
-    assert e <= 2e-2, e
+    check(e, 2e-2)
 
 
 def test_config1_half_mask_bs2_and_graph_replay(sd21, cuda):
@@ -57,7 +58,7 @@ def test_config1_half_mask_bs2_and_graph_replay(sd21, cuda):
         g.replay()
         torch.cuda.synchronize()
     err = rel_l2(out.float().cpu(), ref)
-    assert err <= 2e-2, err
+    check(err, 2e-2)
     assert torch.equal(out, gout)          # the captured HIP graph reproduces the eager result bit for bit
 
 
@@ -121,3 +122,92 @@ def test_headline_forward_takes_the_fused_paths_also_under_graph_capture(sd21, c
             assert torch.equal(gout, out)          # deterministic kernels, same paths: bit-identical
     finally:
         ops.layernorm, ops.groupnorm, ops.LAUNCH_LOG = orig_ln, orig_gn, None
+
+
+def test_config1_half_mask_bs4_the_benchmarked_batch(sd21, cuda):
+    """BASELINE configs[1] exactly as bench.py times it (bs=4, fixed 50 % mask, gated semantics) against the oracle."""
+    model, params = sd21
+    cfg = O.SD21
+    sample, t, ehs = O.synthetic_inputs(cfg, 4, 64, seed=1234)
+    mask = O.fixed_half_mask(cfg)
+    with torch.no_grad():
+        ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, {k: [v.clone() for v in vs] for k, vs in mask.items()}), "gated")
+        model.set_structure({k: [v.to(cuda) for v in vs] for k, vs in mask.items()})
+        out = model(sample.to(cuda), t.to(cuda), ehs.to(cuda)).sample.float().cpu()
+    check(rel_l2(out, ref), 2e-2, "bs=4 vs fp32 oracle")
+    for b in range(4):
+        check(rel_l2(out[b], ref[b]), 2e-2, f"sample {b}")
+
+
+@pytest.mark.parametrize("which", ["half_mask_bs2", "dense_bs1", "random_mask_depth_bs1"])
+def test_gpu_matches_bf16_emulator_tightly(sd21, cuda, which, monkeypatch):
+    """Kernel error separated from format error: the SAME model code runs once on the HIP kernels and once on the CPU
+    emulator of tests/hip_emulator.py, which computes every op in fp32 but rounds to bf16 at exactly the points where the
+    kernels store bf16 (activations, attention probabilities).  What is left is accumulation order and transcendental
+    precision, so the budget is 3e-3 instead of the 2e-2 that bf16 storage costs against the fp32 oracle: a dropped bias, a
+    wrong border class of the beta correction or a mis-indexed gate (>= 1 % effects) cannot hide here."""
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    from tests import hip_emulator
+    model, params = sd21
+    cfg = O.SD21
+    if which == "half_mask_bs2":
+        mask, B, seed = O.fixed_half_mask(cfg), 2, 11
+    elif which == "dense_bs1":
+        mask, B, seed = O.ones_mask(cfg), 1, 12
+    else:
+        mask, B, seed = O.random_mask(cfg, 0.55, 21, n_depth_off=3), 1, 13
+    sample, t, ehs = O.synthetic_inputs(cfg, B, 64, seed=seed)
+    acts_gpu, acts_emu = {}, {}
+
+    def hook(store, name, first):
+        return lambda m, i, o: store.__setitem__(name, (o[0] if first else o).detach().float().cpu())
+    hooks = [model.down_blocks[0].register_forward_hook(hook(acts_gpu, "down0", True)),
+             model.mid_block.register_forward_hook(hook(acts_gpu, "mid", False)),
+             model.up_blocks[3].register_forward_hook(hook(acts_gpu, "up3", False))]
+    try:
+        with torch.no_grad():
+            model.set_structure({k: [v.clone().to(cuda) for v in vs] for k, vs in mask.items()})
+            out = model(sample.to(cuda), t.to(cuda), ehs.to(cuda)).sample.float().cpu()
+    finally:
+        for h in hooks:
+            h.remove()
+    emu = UNet2DConditionModelGated()
+    emu.load_state_dict(params)
+    hip_emulator.install(monkeypatch)
+    emu.down_blocks[0].register_forward_hook(hook(acts_emu, "down0", True))
+    emu.mid_block.register_forward_hook(hook(acts_emu, "mid", False))
+    emu.up_blocks[3].register_forward_hook(hook(acts_emu, "up3", False))
+    with torch.no_grad():
+        emu.set_structure({k: [v.clone() for v in vs] for k, vs in mask.items()})
+        ref = emu(sample, t, ehs).sample.float()
+    for name in ("down0", "mid", "up3"):
+        check(rel_l2(acts_gpu[name], acts_emu[name]), 3e-3, f"{which}: block output {name} vs bf16 emulator")
+    check(rel_l2(out, ref), 3e-3, f"{which}: U-Net output vs bf16 emulator")
+
+
+def test_captured_graph_survives_other_masks_passing_through_the_plan_caches(sd21, cuda):
+    """plans used while a HIP graph is captured are pinned; five other experts run through the same model
+    afterwards (more than the plan caches hold) and the replay still reproduces the captured forward bit for bit."""
+    model, _ = sd21
+    cfg = O.SD21
+    sample, t, ehs = O.synthetic_inputs(cfg, 1, 64, seed=3)
+    s, tt, e_ = sample.to(cuda), t.to(cuda), ehs.to(cuda)
+    mask = O.fixed_half_mask(cfg)
+    with torch.no_grad():
+        model.set_structure({k: [v.to(cuda) for v in vs] for k, vs in mask.items()})
+        want = model(s, tt, e_).sample.clone()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gout = model(s, tt, e_).sample
+        for i in range(5):
+            other = O.random_mask(cfg, 0.4 + 0.08 * i, 100 + i, n_depth_off=i % 3)
+            model.set_structure({k: [v.to(cuda) for v in vs] for k, vs in other.items()})
+            model(s, tt, e_)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()                      # anything the caches let go is really returned to the device
+        junk = torch.full((256 << 20,), 7.0, device=cuda)   # ... and overwritten
+        del junk
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(gout, want)

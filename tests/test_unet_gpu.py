@@ -9,6 +9,7 @@ import torch
 from oracle import unet_oracle as O
 
 pytestmark = pytest.mark.gpu
+from tests.margins import check  # noqa: E402
 TOL = 2e-2
 
 
@@ -46,7 +47,7 @@ def test_dense_ones_mask(tiny, cuda):
     out = run(model, cuda, O.ones_mask(cfg), sample, t, ehs)
     assert out.shape == ref.shape
     e = rel_l2(out, ref)
-    assert e <= TOL, e
+    check(e, TOL)
 
 
 def test_fixed_half_mask_gated_semantics(tiny, cuda):
@@ -58,7 +59,7 @@ def test_fixed_half_mask_gated_semantics(tiny, cuda):
     refp = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "pruned")
     out = run(model, cuda, mask, sample, t, ehs)
     e, ep = rel_l2(out, ref), rel_l2(out, refp)
-    assert e <= TOL, e
+    check(e, TOL)
     assert ep > 2 * e, (e, ep)   # the beta term is really there: we match gated, not pruned, semantics
 
 
@@ -76,7 +77,7 @@ def test_other_resolutions_and_batches(tiny, cuda, batch, latent, masked):
     out = run(model, cuda, mask, sample, t, ehs)
     assert out.shape == ref.shape
     e = rel_l2(out, ref)
-    assert e <= TOL, e
+    check(e, TOL)
     assert U.CAT_STATS["copies"] == 0 and U.CAT_STATS["views"] == sum(len(b.resnets) for b in model.up_blocks)
 
 
@@ -88,7 +89,7 @@ def test_random_hard_masks_with_depth(tiny, cuda, seed, keep, ndoff):
     ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
     out = run(model, cuda, mask, sample, t, ehs)
     e = rel_l2(out, ref)
-    assert e <= TOL, e
+    check(e, TOL)
 
 
 def test_soft_per_sample_masks_and_cfg_tiling(tiny, cuda):
@@ -104,7 +105,7 @@ def test_soft_per_sample_masks_and_cfg_tiling(tiny, cuda):
     ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
     out = run(model, cuda, mask, sample, t, ehs)
     e = rel_l2(out, ref)
-    assert e <= TOL, e
+    check(e, TOL)
 
 
 def test_hard_per_sample_masks(tiny, cuda):
@@ -116,7 +117,7 @@ def test_hard_per_sample_masks(tiny, cuda):
     ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
     out = run(model, cuda, mask, sample, t, ehs)
     e = rel_l2(out, ref)
-    assert e <= TOL, e
+    check(e, TOL)
 
 
 def test_pruned_model_semantics(tiny, cuda):
@@ -134,7 +135,7 @@ def test_pruned_model_semantics(tiny, cuda):
     with torch.no_grad():
         out = pm(sample.to(cuda), t.to(cuda), ehs.to(cuda), return_dict=False)[0]
     e = rel_l2(out.float().cpu(), ref)
-    assert e <= TOL, e
+    check(e, TOL)
 
 
 def test_forward_hooks_see_block_outputs(tiny, cuda):
@@ -151,9 +152,9 @@ def test_forward_hooks_see_block_outputs(tiny, cuda):
         h.remove()
     assert isinstance(seen["down0"], tuple) and len(seen["down0"]) == 2          # (hidden, res_tuple)
     assert seen["mid"].shape == ref_blocks[4].shape
-    assert rel_l2(seen["mid"].float().cpu(), ref_blocks[4]) <= TOL
-    assert rel_l2(seen["up3"].float().cpu(), ref_blocks[8]) <= TOL
-    assert rel_l2(seen["down0"][0].float().cpu(), ref_blocks[0]) <= TOL
+    check(rel_l2(seen["mid"].float().cpu(), ref_blocks[4]), TOL, "ref_blocks[4]")
+    check(rel_l2(seen["up3"].float().cpu(), ref_blocks[8]), TOL, "ref_blocks[8]")
+    check(rel_l2(seen["down0"][0].float().cpu(), ref_blocks[0]), TOL, "ref_blocks[0]")
 
 
 def test_denoise_loop_hip_graph_matches_eager_and_oracle(tiny, cuda):

@@ -4,9 +4,13 @@ Run in the build container only (needs /root/reference; it does not exist on the
     python tests/golden/make_golden.py
 Imports, by file path, exactly these reference modules (nothing is copied into this repository):
     pdm/models/unet/gates.py, pdm/utils/estimation_utils.py, pdm/losses/{contrastive,resource}_loss.py,
-    pdm/utils/metric_utils.py, pdm/models/hypernet/hypernet.py, pdm/models/vq/quantizer.py
+    pdm/utils/metric_utils.py, pdm/models/hypernet/hypernet.py, pdm/models/vq/quantizer.py, pdm/utils/op_counter.py
 hypernet.py / quantizer.py use diffusers only for ModelMixin / ConfigMixin / register_to_config (serialisation);
 an inert in-process shim stands in for those three names and touches no arithmetic.
+op_counter.py (the MAC-counting forward hooks) imports six diffusers / pdm classes only to use them as KEYS of its
+hook table; inert placeholder classes stand in for them, and the reference's own hook functions are then called on
+plain torch.nn modules (conv / linear / GroupNorm / LayerNorm / SiLU) and on an attribute-only stand-in of a gated
+attention module: the numbers recorded are what the reference's code computes for those shapes.
 The committed .npz holds inputs and the reference's outputs only (data, no source).
 """
 import importlib.util
@@ -49,6 +53,82 @@ def install_shims():
     eu = load("pdm.utils.estimation_utils", "pdm/utils/estimation_utils.py")
     utils.estimation_utils = eu
     return eu
+
+
+def macs_hook_vectors():
+    """Run the reference's MAC-counting hooks (pdm/utils/op_counter.py:44-116,259-306) on concrete modules / shapes.
+    Each case is recorded as an int64 row of its defining numbers followed by the MACs the hook reported."""
+    dm = types.ModuleType("diffusers.models"); dm.__path__ = []
+    ap = types.ModuleType("diffusers.models.attention_processor")
+    ap.SpatialNorm = type("SpatialNorm", (), {})
+    ap.Attention = type("Attention", (), {})
+    nz = types.ModuleType("diffusers.models.normalization")
+    nz.AdaGroupNorm = type("AdaGroupNorm", (), {})
+    lo = types.ModuleType("diffusers.models.lora")
+    lo.LoRACompatibleConv = type("LoRACompatibleConv", (), {})
+    lo.LoRACompatibleLinear = type("LoRACompatibleLinear", (), {})
+    sys.modules.update({"diffusers.models": dm, "diffusers.models.attention_processor": ap,
+                        "diffusers.models.normalization": nz, "diffusers.models.lora": lo})
+    pm = types.ModuleType("pdm.models"); pm.__path__ = []
+    pu = types.ModuleType("pdm.models.unet"); pu.__path__ = []
+    pb = types.ModuleType("pdm.models.unet.blocks")
+    pb.GatedAttention = type("GatedAttention", (), {})
+    sys.modules.update({"pdm.models": pm, "pdm.models.unet": pu, "pdm.models.unet.blocks": pb})
+    oc = load("ref_op_counter", "pdm/utils/op_counter.py")
+    out = {}
+
+    def run(hook, mod, *inputs):
+        mod.__macs__ = 0
+        with torch.no_grad():
+            y = mod(*inputs)
+        hook(mod, inputs, y)
+        return int(mod.__macs__)
+
+    rows = []          # [cin, cout, k, stride, pad, bias, H, W] -> macs
+    for cin, cout, k, stride, pad, bias, H, W in [(4, 320, 3, 1, 1, 1, 16, 16), (320, 320, 3, 2, 1, 1, 16, 16),
+                                                  (640, 320, 1, 1, 0, 1, 8, 8), (96, 64, 3, 1, 1, 0, 12, 20),
+                                                  (320, 4, 3, 1, 1, 1, 64, 64)]:
+        m = nn.Conv2d(cin, cout, k, stride, pad, bias=bool(bias))
+        rows.append([cin, cout, k, stride, pad, bias, H, W, run(oc.conv_macs_counter_hook, m, torch.zeros(1, cin, H, W))])
+    out["macs_hook_conv"] = np.asarray(rows, dtype=np.int64)
+    rows = []          # [rows of input, cin, cout, bias] -> macs
+    for L, cin, cout, bias in [(1, 320, 1280, 1), (256, 320, 320, 1), (77, 1024, 640, 0), (4096, 320, 2560, 1), (64, 5120, 1280, 1)]:
+        m = nn.Linear(cin, cout, bias=bool(bias))
+        rows.append([L, cin, cout, bias, run(oc.linear_macs_counter_hook, m, torch.zeros(1, L, cin))])
+    out["macs_hook_linear"] = np.asarray(rows, dtype=np.int64)
+    rows = []          # [C, H, W] -> GroupNorm(32, C) macs, SiLU macs on the same tensor
+    for C, H, W in [(320, 64, 64), (2560, 8, 8), (960, 32, 32)]:
+        x = torch.zeros(1, C, H, W)
+        rows.append([C, H, W, run(oc.bn_macs_counter_hook, nn.GroupNorm(32, C), x), run(oc.silu_macs_counter_hook, nn.SiLU(), x)])
+    out["macs_hook_groupnorm_silu"] = np.asarray(rows, dtype=np.int64)
+    rows = []          # [L, C] -> LayerNorm macs
+    for L, C in [(4096, 320), (64, 1280)]:
+        rows.append([L, C, run(oc.layer_norm_macs_counter_hook, nn.LayerNorm(C), torch.zeros(1, L, C))])
+    out["macs_hook_layernorm"] = np.asarray(rows, dtype=np.int64)
+
+    class AttnStandIn(nn.Module):
+        """the attributes gated_attention_counter_hook reads (op_counter.py:259-306); leaf MACs come from the linear hook"""
+
+        def __init__(self, C, heads, kv_dim):
+            super().__init__()
+            self.to_q, self.to_k, self.to_v = nn.Linear(C, C, bias=False), nn.Linear(kv_dim, C, bias=False), nn.Linear(kv_dim, C, bias=False)
+            self.to_out = nn.ModuleList([nn.Linear(C, C), nn.Identity()])
+            self.heads, self.spatial_norm, self.group_norm, self.norm_cross = heads, None, None, None
+            self.total_macs, self.prunable_macs, self.pruned = 0., 0., False
+    rows = []          # [Lq, Lkv, C, heads, kv_dim] -> total_macs, prunable_macs
+    for Lq, Lkv, C, heads, kv in [(4096, 4096, 320, 5, 320), (4096, 77, 320, 5, 1024), (64, 77, 1280, 20, 1024), (256, 256, 128, 2, 128)]:
+        a = AttnStandIn(C, heads, kv)
+        xq, xkv = torch.zeros(1, Lq, C), torch.zeros(1, Lkv, kv)
+        run(oc.linear_macs_counter_hook, a.to_q, xq)
+        run(oc.linear_macs_counter_hook, a.to_k, xkv)
+        run(oc.linear_macs_counter_hook, a.to_v, xkv)
+        run(oc.linear_macs_counter_hook, a.to_out[0], xq)
+        a.__macs__ = 0
+        oc.gated_attention_counter_hook(a, (xq,), torch.zeros(1, Lq, C))
+        assert a.__macs__ == a.total_macs
+        rows.append([Lq, Lkv, C, heads, kv, int(a.total_macs), int(a.prunable_macs)])
+    out["macs_hook_gated_attention"] = np.asarray(rows, dtype=np.int64)
+    return out
 
 
 def main():
@@ -173,6 +253,8 @@ def main():
     out["q2_macs_template"] = q2.prunable_macs_template.clone()
     q2.eval()
     out["q2_wdn"] = q2.width_depth_normalize(out["q_gst_eval"])
+
+    out.update(macs_hook_vectors())
 
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"),
                         **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})

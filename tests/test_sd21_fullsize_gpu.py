@@ -10,6 +10,18 @@ pytestmark = pytest.mark.gpu
 from tests.margins import check  # noqa: E402
 
 
+# Whole network, GPU vs bf16 emulator (same rounding points).  Measured on MI355X (profiles/r2_parity_margins.json): the two
+# bf16 trajectories decorrelate with depth -- fp32 accumulation-order differences flip individual bf16 roundings and ~60
+# layers amplify them -- so at the output they are as far from each other (1.35e-2) as each is from the fp32 oracle
+# (1.38e-2 / 1.41e-2).  A tight whole-network bound therefore has to be RELATIVE: the GPU's error against the oracle must
+# equal the format's own error (emulator vs oracle) within 5 % (measured 0.97-1.00); a systematic defect adds in
+# quadrature, so anything >= 0.5 % of the signal trips it.  The absolute 3e-3 bound is enforced where the trajectories
+# have not yet diverged: per sub-block on identical inputs (test_every_block_matches_bf16_emulator).
+EMU_TOL = 2e-2
+RATIO_TOL = 1.05
+BLOCK_EMU_TOL = 3e-3
+
+
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
@@ -140,12 +152,12 @@ def test_config1_half_mask_bs4_the_benchmarked_batch(sd21, cuda):
 
 
 @pytest.mark.parametrize("which", ["half_mask_bs2", "dense_bs1", "random_mask_depth_bs1"])
-def test_gpu_matches_bf16_emulator_tightly(sd21, cuda, which, monkeypatch):
-    """Kernel error separated from format error: the SAME model code runs once on the HIP kernels and once on the CPU
-    emulator of tests/hip_emulator.py, which computes every op in fp32 but rounds to bf16 at exactly the points where the
-    kernels store bf16 (activations, attention probabilities).  What is left is accumulation order and transcendental
-    precision, so the budget is 3e-3 instead of the 2e-2 that bf16 storage costs against the fp32 oracle: a dropped bias, a
-    wrong border class of the beta correction or a mis-indexed gate (>= 1 % effects) cannot hide here."""
+def test_gpu_error_equals_the_bf16_format_error(sd21, cuda, which, monkeypatch):
+    """Kernel error separated from format error, whole network: the SAME model code runs once on the HIP kernels and once on
+    the CPU emulator of tests/hip_emulator.py, which computes every op in fp32 but rounds to bf16 at exactly the points
+    where the kernels store bf16 (activations, attention probabilities).  At three block outputs and at the U-Net output the
+    GPU's distance to the fp32 oracle must equal the emulator's distance to the oracle within 5 %: a dropped bias, a wrong
+    border class of the beta correction or a mis-indexed gate (>= 0.5 % effects) cannot hide under the 2e-2 budget."""
     from diffusion_pruning_amd.unet import UNet2DConditionModelGated
     from tests import hip_emulator
     model, params = sd21
@@ -180,9 +192,111 @@ def test_gpu_matches_bf16_emulator_tightly(sd21, cuda, which, monkeypatch):
     with torch.no_grad():
         emu.set_structure({k: [v.clone() for v in vs] for k, vs in mask.items()})
         ref = emu(sample, t, ehs).sample.float()
-    for name in ("down0", "mid", "up3"):
-        check(rel_l2(acts_gpu[name], acts_emu[name]), 3e-3, f"{which}: block output {name} vs bf16 emulator")
-    check(rel_l2(out, ref), 3e-3, f"{which}: U-Net output vs bf16 emulator")
+    with torch.no_grad():
+        ora, blocks = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, {k: [v.clone() for v in vs] for k, vs in mask.items()}),
+                                     "gated", return_blocks=True)
+    from tests import margins
+    errs = {}
+    for name, idx in (("down0", 0), ("mid", 4), ("up3", 8), ("out", None)):
+        g, e, r = (out, ref, ora) if idx is None else (acts_gpu[name], acts_emu[name], blocks[idx])
+        errs[name] = (rel_l2(g, e), rel_l2(g, r), rel_l2(e, r))
+    fails = []
+    for name, (ge, go, eo) in errs.items():
+        for what, v, tol in ((f"{which}: {name} GPU vs bf16 emulator", ge, EMU_TOL),
+                             (f"{which}: {name} GPU vs fp32 oracle", go, 2e-2),
+                             (f"{which}: {name} bf16 emulator vs fp32 oracle (the format's own error)", eo, 2e-2),
+                             (f"{which}: {name} GPU error / format error", go / eo, RATIO_TOL)):
+            try:
+                check(v, tol, what)
+            except AssertionError as ex:
+                fails.append(str(ex))
+    assert not fails, fails
+
+
+@pytest.mark.parametrize("maskname", ["half", "dense", "soft_per_sample"])
+def test_every_block_matches_bf16_emulator(sd21, cuda, maskname, monkeypatch):
+    """Per sub-block, identical inputs: each of the 22 resnets and 16 transformers of SD-2.1 (and the down/up-samplers) runs
+    on the HIP kernels and on the bf16 emulator from the SAME seeded bf16 input, with a compacting hard mask, the dense
+    mask and per-sample soft masks (epilogue-gated dense compute + depth lerp).  Rel-L2 <= 3e-3 each (bf16 code-point flips
+    only); the fp32-oracle tolerance of these blocks would be ~4x looser."""
+    from diffusion_pruning_amd import unet as U
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    from tests import hip_emulator
+    model, params = sd21
+    cfg = O.SD21
+    B = 2
+    if maskname == "half":
+        mask = O.fixed_half_mask(cfg)
+    elif maskname == "dense":
+        mask = O.ones_mask(cfg)
+    else:
+        g = torch.Generator().manual_seed(4)
+        st = O.get_structure(cfg)
+        mask = {"width": [torch.rand(B, w, generator=g) * 0.9 + 0.1 for sub in st["width"] for w in sub],
+                "depth": [torch.rand(B, generator=g) for sub in st["depth"] for d in sub if d == 1]}
+    emu = UNet2DConditionModelGated()
+    emu.load_state_dict(params)
+    model.set_structure({k: [v.clone().to(cuda) for v in vs] for k, vs in mask.items()})
+    emu.set_structure({k: [v.clone() for v in vs] for k, vs in mask.items()})
+    gen = torch.Generator().manual_seed(99)
+    T = model.time_embedding.linear_1.out_features
+    temb = torch.randn(B, T, generator=gen)
+    ehs = torch.randn(B, 77, cfg.cross_attention_dim, generator=gen)
+    level_hw = {}                               # channels -> map side, from the SD-2.1 layout at 64x64 latents
+    jobs = []
+    hw = 64
+    for bi, blk in enumerate(model.down_blocks):
+        for ri in range(len(blk.resnets)):
+            jobs.append((f"down{bi}.resnets.{ri}", "res", hw))
+            if blk.has_cross_attention:
+                jobs.append((f"down{bi}.attentions.{ri}", "attn", hw))
+        if blk.downsamplers is not None:
+            jobs.append((f"down{bi}.downsamplers.0", "down", hw))
+            hw //= 2
+    jobs += [("mid.resnets.0", "res", hw), ("mid.attentions.0", "attn", hw), ("mid.resnets.1", "res", hw)]
+    for bi, blk in enumerate(model.up_blocks):
+        for ri in range(len(blk.resnets)):
+            jobs.append((f"up{bi}.resnets.{ri}", "res", hw))
+            if blk.has_cross_attention:
+                jobs.append((f"up{bi}.attentions.{ri}", "attn", hw))
+        if blk.upsamplers is not None:
+            jobs.append((f"up{bi}.upsamplers.0", "up", hw))
+            hw *= 2
+
+    def get(m, path):
+        head, rest = path.split(".", 1)
+        root = m.mid_block if head == "mid" else (m.down_blocks if head.startswith("down") else m.up_blocks)[int(head[-1])]
+        return root.get_submodule(rest)
+
+    def run_one(mod, kind, x, dev):
+        x = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            if kind == "res":
+                y = mod(x, temb.to(dev))
+            elif kind == "attn":
+                y = mod(x, encoder_hidden_states=ehs.to(dev), return_dict=False)[0]
+            else:
+                y = mod(x)
+        return y.float().cpu()
+
+    results = []
+    for path, kind, side in jobs:
+        gm, em = get(model, path), get(emu, path)
+        cin = gm.in_channels if kind != "down" and kind != "up" else gm.conv.in_channels
+        x = torch.randn(B, cin, side, side, generator=gen)
+        y_gpu = run_one(gm, kind, x, cuda)
+        with monkeypatch.context() as mp:
+            hip_emulator.install(mp)
+            y_emu = run_one(em, kind, x, torch.device("cpu"))
+        assert y_gpu.shape == y_emu.shape, path
+        results.append((rel_l2(y_gpu, y_emu), path))
+    fails = []
+    for e, path in results:
+        try:
+            check(e, BLOCK_EMU_TOL, f"{maskname}: {path} GPU vs bf16 emulator (same input)")
+        except AssertionError as ex:
+            fails.append(str(ex))
+    assert not fails, fails
 
 
 def test_captured_graph_survives_other_masks_passing_through_the_plan_caches(sd21, cuda):

@@ -44,7 +44,14 @@ def test_gate_gradients_full_size(cuda):
     per = [rel_l2(a.grad.float().cpu(), b.grad) for a, b in zip(w_dev + d_dev, w_ref + d_ref)]
     check(rel_l2(got, ref), 6e-2, "all gate gradients")
     check(sorted(per)[len(per) // 2], 8e-2, "median gate tensor")
-    check(max(per), 0.3, "worst gate tensor")
+    # Worst tensor: the width gate of a resnet scales exactly one GroupNorm group of norm2's input, and GroupNorm is
+    # invariant to that scale (up to eps), so its true gradient is ~0 (oracle: 1e-3 against a total norm of 282) and comes
+    # out of a cancellation of O(1) terms -- its relative error is ill-conditioned by construction (measured 1e2 with an
+    # ABSOLUTE error of 0.1).  Each tensor's error is therefore taken relative to max(its own norm, the RMS tensor norm).
+    floor = float(ref.norm()) / (len(per) ** 0.5)
+    worst = max(float((a.grad.float().cpu().double() - b.grad.double()).norm()) / max(float(b.grad.norm()), floor)
+                for a, b in zip(w_dev + d_dev, w_ref + d_ref))
+    check(worst, 0.15, "worst gate tensor (error / max(own norm, RMS tensor norm))")
 
 
 def test_expert_parameter_gradients_full_size(cuda):

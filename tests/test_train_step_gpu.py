@@ -23,19 +23,24 @@ class _Pass(nn.Module):
 
 
 class OracleUNetAdapter:
-    """Reference-API facade over the oracle: set_structure / __call__ / calc_macs / hookable blocks."""
+    """Reference-API facade over the oracle: set_structure / __call__ / calc_macs / hookable blocks.  MAC accounting is
+    oracle/macs_oracle.py -- an implementation independent of the product's macs.py -- so the resource / std / max loss
+    terms of the two steps are a real comparison."""
 
-    def __init__(self, params, cfg, macs_model):
-        self.params, self.cfg, self.macs_model = params, cfg, macs_model
+    def __init__(self, params, cfg):
+        from oracle import macs_oracle
+        self.params, self.cfg, self.M = params, cfg, macs_oracle
         self.down_blocks = nn.ModuleList([_Pass() for _ in range(4)])
         self.mid_block = _Pass()
         self.up_blocks = nn.ModuleList([_Pass() for _ in range(4)])
         self.gates = {}
+        self.latent = None
+        self.prunable_macs_list = None
+        self.resource_info_dict = None
 
     def set_structure(self, sep):
         w, d = list(sep["width"]), list(sep["depth"])
         self.gates = O.assign_gates(self.cfg, {"width": list(w), "depth": list(d)})
-        self.macs_model.set_structure({"width": list(w), "depth": list(d)})
 
     def __call__(self, sample, t, ehs):
         out, blocks = O.unet_forward(self.params, self.cfg, sample, t, ehs, self.gates, "gated", return_blocks=True)
@@ -52,18 +57,15 @@ class OracleUNetAdapter:
         return r
 
     def calc_macs(self):
-        return self.macs_model.calc_macs()
+        return self.M.calc_macs(self.cfg, self.latent, self.gates)
 
     def count_macs(self, n):
-        return self.macs_model.count_macs(n)
-
-    @property
-    def prunable_macs_list(self):
-        return self.macs_model.prunable_macs_list
-
-    @property
-    def resource_info_dict(self):
-        return self.macs_model.resource_info_dict
+        """Pruner.count_macs (trainer.py:1256-1306) with the all-ones structure the caller installed"""
+        self.latent = n
+        info = self.calc_macs()
+        self.prunable_macs_list = [[e / info["prunable_macs"] for e in sub] for sub in self.M.prunable_macs_list(self.cfg, n)]
+        self.resource_info_dict = info
+        return info
 
 
 def build(cuda):
@@ -74,18 +76,17 @@ def build(cuda):
     kw = dict(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads, cross_attention_dim=cfg.cross_attention_dim)
     unet = UNet2DConditionModelGated(**kw).init_synthetic(seed=0)
     params = {k: v.detach().clone() for k, v in unet.state_dict().items()}
-    macs_model = UNet2DConditionModelGated(**kw)           # CPU instance: only its (pure-torch) MAC accounting is used
     structure = unet.get_structure()
     torch.manual_seed(11)
     hn = HyperStructure(structure=structure, input_dim=32, wn_flag=False, linear_bias=True)
     qz = StructureVectorQuantizer(n_e=4, structure=structure, temperature=0.4, base=3, depth_order=DEPTH_ORDER,
                                   resource_aware_normalization=False, optimal_transport=True)
-    return cfg, unet, params, macs_model, hn, qz
+    return cfg, unet, params, hn, qz
 
 
 def test_pruning_step_matches_oracle_driven_step(cuda):
     from diffusion_pruning_amd.train_step import PrunerStep, PruningLossConfig, synthetic_batch
-    cfg, unet, params, macs_model, hn, qz = build(cuda)
+    cfg, unet, params, hn, qz = build(cuda)
     hn_ref, qz_ref = copy.deepcopy(hn), copy.deepcopy(qz)
     unet.to(cuda).freeze()
     hn.to(cuda); qz.to(cuda)
@@ -102,7 +103,7 @@ def test_pruning_step_matches_oracle_driven_step(cuda):
     out["loss"].backward()
     torch.cuda.synchronize()
 
-    ref_unet = OracleUNetAdapter(params, cfg, macs_model)
+    ref_unet = OracleUNetAdapter(params, cfg)
     ref = PrunerStep(ref_unet, hn_ref, qz_ref, lcfg)
     hn_ref.train(); qz_ref.train()
     ref.count_macs(16)
@@ -124,7 +125,7 @@ def test_pruning_step_matches_oracle_driven_step(cuda):
 
 def test_two_optimizer_steps_change_the_router(cuda):
     from diffusion_pruning_amd.train_step import PrunerStep, synthetic_batch
-    cfg, unet, params, macs_model, hn, qz = build(cuda)
+    cfg, unet, params, hn, qz = build(cuda)
     unet.to(cuda).freeze()
     hn.to(cuda); qz.to(cuda)
     step = PrunerStep(unet, hn, qz)
@@ -147,7 +148,7 @@ def test_graphed_step_equals_eager_step(cuda):
     """GraphedPrunerStep (both U-Net passes replayed from HIP graphs, chain rule closed eagerly) gives the eager step's
     losses and router gradients, on two different batches through the same captured graphs."""
     from diffusion_pruning_amd.train_step import GraphedPrunerStep, PrunerStep, synthetic_batch
-    cfg, unet, params, macs_model, hn, qz = build(cuda)
+    cfg, unet, params, hn, qz = build(cuda)
     unet.to(cuda).freeze()
     hn.to(cuda); qz.to(cuda)
     hn.train(); qz.train()

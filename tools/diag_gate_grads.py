@@ -1,0 +1,37 @@
+"""Diagnostic: per-gate-tensor gradient error of the full-size pruning-step backward vs oracle autograd (prints the worst)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import unet_oracle as O
+from tests.test_train_gpu import soft_gates
+from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+cuda = torch.device("cuda:0")
+cfg = O.SD21
+torch.set_num_threads(32)
+model = UNet2DConditionModelGated().init_synthetic(seed=0)
+params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+model.to(cuda).freeze()
+sample, t, ehs = O.synthetic_inputs(cfg, 1, 64, seed=21)
+R = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5))
+w_ref, d_ref = soft_gates(cfg, 1, 77)
+out_ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, {"width": list(w_ref), "depth": list(d_ref)}), "gated")
+(out_ref * R).sum().backward()
+w_dev, d_dev = soft_gates(cfg, 1, 77, cuda)
+model.set_structure({"width": list(w_dev), "depth": list(d_dev)})
+out = model(sample.to(cuda), t.to(cuda), ehs.to(cuda)).sample
+(out.float() * R.to(cuda)).sum().backward()
+torch.cuda.synchronize()
+rows = []
+for i, (a, b) in enumerate(zip(w_dev + d_dev, w_ref + d_ref)):
+    kind = "w" if i < len(w_dev) else "d"
+    rows.append((rel(a.grad.float().cpu(), b.grad), kind, i if kind == "w" else i - len(w_dev), tuple(b.shape), float(b.grad.norm()), float(a.grad.float().norm())))
+tot = float(torch.cat([g.grad.flatten() for g in w_ref + d_ref]).norm())
+print("total ref grad norm", tot)
+for r in sorted(rows, reverse=True)[:15]:
+    print("rel %.3e  %s%-3d shape %-10s ref-norm %.3e got-norm %.3e" % r)
+st = O.get_structure(cfg)
+print("width structure:", st["width"])

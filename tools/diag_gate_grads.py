@@ -31,6 +31,15 @@ for i, (a, b) in enumerate(zip(w_dev + d_dev, w_ref + d_ref)):
     rows.append((rel(a.grad.float().cpu(), b.grad), kind, i if kind == "w" else i - len(w_dev), tuple(b.shape), float(b.grad.norm()), float(a.grad.float().norm())))
 tot = float(torch.cat([g.grad.flatten() for g in w_ref + d_ref]).norm())
 print("total ref grad norm", tot)
+floor = tot / (len(rows) ** 0.5)
+norm_rows = []
+for i, (a, b) in enumerate(zip(w_dev + d_dev, w_ref + d_ref)):
+    kind = "w" if i < len(w_dev) else "d"
+    err = float((a.grad.float().cpu().double() - b.grad.double()).norm())
+    norm_rows.append((err / max(float(b.grad.norm()), floor), kind, i if kind == "w" else i - len(w_dev), err, float(b.grad.norm())))
+print("floor (RMS tensor norm)", floor)
+for r in sorted(norm_rows, reverse=True)[:12]:
+    print("normalised err %.3e  %s%-3d abs err %.3e ref-norm %.3e" % r)
 for r in sorted(rows, reverse=True)[:15]:
     print("rel %.3e  %s%-3d shape %-10s ref-norm %.3e got-norm %.3e" % r)
 st = O.get_structure(cfg)

@@ -97,6 +97,7 @@ class GateBwdParams(Structure):
         ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("groups", c_int32),
         ("gate", c_void_p), ("gate_B", c_int32),
         ("dgate_partial", c_void_p),
+        ("dgate", c_void_p),
     ]
 
 
@@ -107,6 +108,19 @@ class GegluParams(Structure):
         ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("groups", c_int32),
         ("gate", c_void_p), ("gate_B", c_int32),
         ("dgate_partial", c_void_p),
+        ("backward", c_int32),
+        ("dgate", c_void_p),
+    ]
+
+
+class DepthLerpParams(Structure):
+    _fields_ = [
+        ("x_in", c_void_p), ("ld_in", c_int64), ("x_out", c_void_p), ("ld_out", c_int64), ("y", c_void_p), ("ld_y", c_int64),
+        ("dy", c_void_p), ("ld_dy", c_int64), ("d_in", c_void_p), ("ld_d_in", c_int64), ("d_out", c_void_p), ("ld_d_out", c_int64),
+        ("B", c_int32), ("HW", c_int32), ("C", c_int32),
+        ("d", c_void_p), ("d_B", c_int32),
+        ("dd_partial", c_void_p),
+        ("dd", c_void_p),
         ("backward", c_int32),
     ]
 
@@ -189,6 +203,7 @@ EXPORTS = [
     ("aptp_attention", c_int, [POINTER(AttentionParams), c_void_p]),
     ("aptp_gate_bwd", c_int, [POINTER(GateBwdParams), c_void_p]),
     ("aptp_geglu", c_int, [POINTER(GegluParams), c_void_p]),
+    ("aptp_depth_lerp", c_int, [POINTER(DepthLerpParams), c_void_p]),
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),
     ("aptp_layernorm_bwd", c_int, [POINTER(LayerNormBwdParams), c_void_p]),
     ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),

@@ -23,24 +23,32 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 class ConvFn(Function):
-    """y = conv(x, w) + bias (+ rowbias[b]) on [B,H,W,C] (or tokens [B,L,C]); backward = dgrad through the same kernel."""
+    """y = conv(x, w) + bias (+ rowbias[b]) (+ residual) on [B,H,W,C] (or tokens [B,L,C]); backward = dgrad through the same
+    kernel; the residual (the ``+ x`` of a resnet / transformer sub-block, blocks.py:369,791,815,823) is added in the GEMM's
+    epilogue and its gradient is dy itself -- no elementwise add kernel in either direction."""
 
     @staticmethod
     def forward(ctx, x, pw: PackedWeight, get_bwd: Callable[[], PackedWeight], stride: int, pad: int, ups: int,
-                rowbias: Optional[torch.Tensor], out_f32: bool):
+                rowbias: Optional[torch.Tensor], out_f32: bool, residual: Optional[torch.Tensor]):
         tokens = x.dim() == 3
         xin = x.unsqueeze(2) if tokens else x
-        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, rowbias=rowbias, out_f32=out_f32)
+        res = None
+        if residual is not None:
+            res = residual.unsqueeze(2) if tokens else residual
+        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, rowbias=rowbias, out_f32=out_f32, residual=res)
         ctx.meta = (pw, get_bwd, stride, pad, ups, tokens)
         return y.squeeze(2) if tokens else y
 
     @staticmethod
     def backward(ctx, dy):
         pw, get_bwd, stride, pad, ups, tokens = ctx.meta
+        dres = dy if ctx.needs_input_grad[8] else None
         if not ctx.needs_input_grad[0]:
-            return (None,) * 8
+            return (None,) * 8 + (dres,)
         pwb = get_bwd()
         dy = _c(dy.to(torch.bfloat16))
+        if dres is not None:
+            dres = dy
         if tokens:
             dy = dy.unsqueeze(2)
         k = pw.KH
@@ -51,12 +59,14 @@ class ConvFn(Function):
             if ups == 1:                                                            # adjoint of the nearest x2 upsample
                 B, H2, W2, C = dx.shape
                 dx = dx.view(B, H2 // 2, 2, W2 // 2, 2, C).float().sum(dim=(2, 4)).to(torch.bfloat16)
-        return (dx.squeeze(2) if tokens else dx,) + (None,) * 7
+        return (dx.squeeze(2) if tokens else dx,) + (None,) * 7 + (dres,)
 
 
-def conv(x, pw, get_bwd, stride=1, pad=None, ups=0, rowbias=None, out_f32=False):
+def conv(x, pw, get_bwd, stride=1, pad=None, ups=0, rowbias=None, out_f32=False, residual=None):
     pad = pw.KH // 2 if pad is None else pad
-    return ConvFn.apply(x, pw, get_bwd, stride, pad, ups, rowbias, out_f32)
+    if residual is not None and not (residual.dtype == torch.bfloat16 and not out_f32):
+        return ConvFn.apply(x, pw, get_bwd, stride, pad, ups, rowbias, out_f32, None) + residual
+    return ConvFn.apply(x, pw, get_bwd, stride, pad, ups, rowbias, out_f32, residual)
 
 
 class GateFn(Function):
@@ -169,15 +179,27 @@ class GegluFn(Function):
         return dhg, (dgate.to(gate.dtype) if (gate is not None and ctx.needs_input_grad[1]) else None)
 
 
+class DepthLerpFn(Function):
+    """DepthGate.forward (gates.py:36-42): (1-d)*x_in + d*out with d [Bg] tiled over the batch -- one launch forward, one
+    (+ its reduction) backward, gradient w.r.t. d in fp32."""
+
+    @staticmethod
+    def forward(ctx, x_in, out, d):
+        out = _c(out)
+        y = ops.depth_lerp(x_in, out, d)
+        ctx.save_for_backward(x_in, out, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_in, out, d = ctx.saved_tensors
+        d_in, d_out, dd = ops.depth_lerp_bwd(_c(dy.to(torch.bfloat16)), x_in, out, d)
+        return (d_in if ctx.needs_input_grad[0] else None, d_out if ctx.needs_input_grad[1] else None,
+                dd.reshape(d.shape).to(d.dtype) if ctx.needs_input_grad[2] else None)
+
+
 def depth_lerp(x_in: torch.Tensor, out: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
-    """DepthGate.forward (gates.py:36-42): (1-d)*x_in + d*out with d [Bg] tiled over the batch; tiny elementwise glue,
-    differentiable w.r.t. d through PyTorch's own elementwise kernels."""
-    B = out.shape[0]
-    dm = d.reshape(-1)
-    if dm.shape[0] != B:
-        dm = dm.repeat(B // dm.shape[0])
-    dm = dm.view(B, *([1] * (out.dim() - 1)))
-    return ((1.0 - dm) * x_in.float() + dm * out.float()).to(torch.bfloat16)
+    return DepthLerpFn.apply(x_in, out, d)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -201,6 +201,114 @@ __global__ __launch_bounds__(256) void geglu_kernel(const GegluK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Second stage of the per-gate reductions: out[bg, g] = sum over the batch rows that share gate row bg (CFG tiling:
+// b = rep*gate_B + bg) and over the row chunks of partial[b, chunk, g].  One workgroup per gate row, fixed summation
+// order (slice s of S = 256 / Gs threads takes chunks s, s+S, ...; slices are folded 0..S-1 by one thread per g), so the
+// result does not depend on scheduling.  Replaces two torch reductions per gate (a strided sum over the chunk axis and
+// a sum over the batch repetitions) by one 2-3 us launch inside the same ABI call.
+// ------------------------------------------------------------------------------------------------------------
+struct FoldK { const float* partial; float* out; int B, nchunk, G, gate_B; };
+
+__global__ __launch_bounds__(256) void fold_partials_kernel(const FoldK p) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x, bg = blockIdx.x;
+  const int Gs = p.G <= 256 ? p.G : 256;            // (G <= 128 by fill_rowk)
+  const int S = 256 / Gs;
+  const int g = tid % Gs, s = tid / Gs;
+  float v = 0.f;
+  if (s < S) {
+    const int reps = p.B / p.gate_B;
+    for (int rep = 0; rep < reps; ++rep) {
+      const float* w = p.partial + (int64_t)(rep * p.gate_B + bg) * p.nchunk * p.G + g;
+      for (int c = s; c < p.nchunk; c += S) v += w[(int64_t)c * p.G];
+    }
+  }
+  red[tid] = v;
+  __syncthreads();
+  if (tid < Gs) {
+    float a = 0.f;
+    for (int q = 0; q < S; ++q) a += red[q * Gs + tid];
+    p.out[(int64_t)bg * p.G + tid] = a;
+  }
+}
+
+void launch_fold(const float* partial, float* out, int B, int nchunk, int G, int gate_B, hipStream_t s) {
+  FoldK f{partial, out, B, nchunk, G, gate_B};
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(gate_B), dim3(256), 0, s, f);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// DepthGate (gates.py:36-42) in its training form: y = (1 - d[b % dB]) * x_in + d[b % dB] * x_out.
+//   backward: d_out = dy * d,  d_in = dy * (1 - d),  dd_partial[b, chunk] = sum dy * (x_out - x_in)
+// Same row-chunk streaming layout as the gate kernels (one "group" = all channels).
+// ------------------------------------------------------------------------------------------------------------
+struct LerpK {
+  RowK r;
+  const __bf16* xin; int64_t ldin; const __bf16* xout; int64_t ldout; __bf16* y; int64_t ldy;
+  const __bf16* dy; int64_t lddy; __bf16* din; int64_t lddin; __bf16* dout; int64_t lddout;
+  const float* d; int dB; float* partial;
+};
+
+template <int NP, bool BWD>
+__global__ __launch_bounds__(256) void depth_lerp_kernel(const LerpK p) {
+  __shared__ float red[1][6144];
+  const RowK& k = p.r;
+  const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = (int)(((int64_t)k.HW * chunk) / k.nchunk), r1 = (int)(((int64_t)k.HW * (chunk + 1)) / k.nchunk);
+  const int rl = tid / k.TPR, ot = tid - rl * k.TPR;
+  const bool active = rl < k.RPAR;
+  const float dv = p.d[b % p.dB], iv = 1.0f - dv;
+  float acc[NP][8];
+#pragma unroll
+  for (int pg = 0; pg < NP; ++pg)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[pg][e] = 0.f;
+  if (active) {
+    const int64_t row0 = (int64_t)b * k.HW;
+    for (int r = r0 + rl; r < r1; r += k.RPAR) {
+#pragma unroll
+      for (int pg = 0; pg < NP; ++pg) {
+        const int o = ot + pg * 256;
+        if (o < k.CO) {
+          const u32x4 qi = *reinterpret_cast<const u32x4*>(p.xin + (row0 + r) * p.ldin + o * 8);
+          const u32x4 qo = *reinterpret_cast<const u32x4*>(p.xout + (row0 + r) * p.ldout + o * 8);
+          float xi[8], xo[8], v[8];
+          unpack8(qi, xi); unpack8(qo, xo);
+          if (!BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = iv * xi[e] + dv * xo[e];
+            *reinterpret_cast<u32x4*>(p.y + (row0 + r) * p.ldy + o * 8) = pack8(v);
+          } else {
+            const u32x4 qd = *reinterpret_cast<const u32x4*>(p.dy + (row0 + r) * p.lddy + o * 8);
+            float g[8], w[8];
+            unpack8(qd, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc[pg][e] += g[e] * (xo[e] - xi[e]); v[e] = g[e] * dv; w[e] = g[e] * iv; }
+            *reinterpret_cast<u32x4*>(p.dout + (row0 + r) * p.lddout + o * 8) = pack8(v);
+            *reinterpret_cast<u32x4*>(p.din + (row0 + r) * p.lddin + o * 8) = pack8(w);
+          }
+        }
+      }
+    }
+  }
+  if (BWD) {
+    const int CP = k.TPR * 8 * NP;
+    if (active) {
+#pragma unroll
+      for (int pg = 0; pg < NP; ++pg) {
+        const int o = ot + pg * 256;
+        if (o < k.CO) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) red[0][rl * CP + o * 8 + e] = acc[pg][e];
+        }
+      }
+    }
+    __syncthreads();
+    fold_channels_to_groups(k, red, 1, CP, tid, p.partial + ((int64_t)b * k.nchunk + chunk));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // GroupNorm(+SiLU) backward.  With xh = (x - mean)*rstd, z = xh*gamma + beta, y = act(z):
 //   dxh = dy*act'(z)*gamma;  per (b, group): S1 = sum dxh, S2 = sum dxh*xh;  dx = rstd*(dxh - S1/n - xh*S2/n)
 // stage 1 (gn_bwd_stats): folds the forward statistics partials, writes (S1, S2) partials per row chunk
@@ -567,6 +675,11 @@ extern "C" int aptp_gate_bwd(const AptpGateBwdParams* p, aptp_stream_t stream) {
   else if (k.r.CO <= 512) hipLaunchKernelGGL(gate_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
   else hipLaunchKernelGGL(gate_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, k);
   APTP_LAUNCH_CHECK();
+  if (p->dgate) {
+    APTP_CHECK(p->B % p->gate_B == 0, "gate_bwd: B must be a multiple of gate_B");
+    launch_fold(p->dgate_partial, p->dgate, p->B, k.r.nchunk, p->groups, p->gate_B, (hipStream_t)stream);
+    APTP_LAUNCH_CHECK();
+  }
   return APTP_OK;
 }
 
@@ -596,6 +709,44 @@ extern "C" int aptp_geglu(const AptpGegluParams* p, aptp_stream_t stream) {
     else hipLaunchKernelGGL((geglu_kernel<3, true>), grid, dim3(256), 0, s, k);
   }
   APTP_LAUNCH_CHECK();
+  if (p->backward && p->dgate) {
+    APTP_CHECK(p->gate && p->B % p->gate_B == 0, "geglu: dgate needs a gate and B a multiple of gate_B");
+    launch_fold(p->dgate_partial, p->dgate, p->B, k.r.nchunk, p->groups, p->gate_B, s);
+    APTP_LAUNCH_CHECK();
+  }
+  return APTP_OK;
+}
+
+extern "C" int aptp_depth_lerp(const AptpDepthLerpParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->x_in && p->x_out && p->d && p->d_B > 0, "depth_lerp: null pointer");
+  LerpK k;
+  const int rc = fill_rowk(k.r, p->B, p->HW, p->C, 1, "depth_lerp");
+  if (rc) return rc;
+  APTP_CHECK(p->C % 8 == 0 && p->ld_in % 8 == 0 && p->ld_out % 8 == 0 && ALIGN16(p->x_in) && ALIGN16(p->x_out) && p->B % p->d_B == 0,
+             "depth_lerp: C and ld must be multiples of 8, bases 16-byte aligned, B a multiple of d_B");
+  k.xin = (const __bf16*)p->x_in; k.ldin = p->ld_in; k.xout = (const __bf16*)p->x_out; k.ldout = p->ld_out;
+  k.y = (__bf16*)p->y; k.ldy = p->ld_y;
+  k.dy = (const __bf16*)p->dy; k.lddy = p->ld_dy; k.din = (__bf16*)p->d_in; k.lddin = p->ld_d_in;
+  k.dout = (__bf16*)p->d_out; k.lddout = p->ld_d_out;
+  k.d = p->d; k.dB = p->d_B; k.partial = p->dd_partial;
+  dim3 grid(k.r.nchunk, p->B);
+  hipStream_t s = (hipStream_t)stream;
+  if (!p->backward) {
+    APTP_CHECK(p->y && p->ld_y % 8 == 0 && ALIGN16(p->y), "depth_lerp: y");
+    if (k.r.CO <= 256) hipLaunchKernelGGL((depth_lerp_kernel<1, false>), grid, dim3(256), 0, s, k);
+    else if (k.r.CO <= 512) hipLaunchKernelGGL((depth_lerp_kernel<2, false>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((depth_lerp_kernel<3, false>), grid, dim3(256), 0, s, k);
+    APTP_LAUNCH_CHECK();
+  } else {
+    APTP_CHECK(p->dy && p->d_in && p->d_out && p->dd_partial && p->dd && p->ld_dy % 8 == 0 && p->ld_d_in % 8 == 0 && p->ld_d_out % 8 == 0
+               && ALIGN16(p->dy) && ALIGN16(p->d_in) && ALIGN16(p->d_out), "depth_lerp: backward operands");
+    if (k.r.CO <= 256) hipLaunchKernelGGL((depth_lerp_kernel<1, true>), grid, dim3(256), 0, s, k);
+    else if (k.r.CO <= 512) hipLaunchKernelGGL((depth_lerp_kernel<2, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((depth_lerp_kernel<3, true>), grid, dim3(256), 0, s, k);
+    APTP_LAUNCH_CHECK();
+    launch_fold(p->dd_partial, p->dd, p->B, k.r.nchunk, 1, p->d_B, s);
+    APTP_LAUNCH_CHECK();
+  }
   return APTP_OK;
 }
 

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import UnetEpilogueParams, UnetPrologueParams
-from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, GateBwdParams,
+from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams,
                    GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
                    ColsumParams, LayerNormPgradParams)
 
@@ -685,12 +685,12 @@ def gate_bwd(dy: torch.Tensor, y0: torch.Tensor, gate: torch.Tensor):
     dx = torch.empty_like(dy, memory_format=torch.contiguous_format)
     nchunk = lib.aptp_groupnorm_nchunk(HW)
     part = torch.empty(B, nchunk, G, dtype=torch.float32, device=dy.device)
+    dgate = torch.empty(Bg, G, dtype=torch.float32, device=dy.device)
     p = GateBwdParams()
     p.dy, p.lddy, p.y0, p.ldy0, p.dx, p.lddx = dy.data_ptr(), lddy, y0.data_ptr(), ldy0, dx.data_ptr(), C
     p.B, p.HW, p.C, p.groups = B, HW, C, G
-    p.gate, p.gate_B, p.dgate_partial = gate.data_ptr(), Bg, part.data_ptr()
-    _lib.check(lib.aptp_gate_bwd(ctypes.byref(p), _stream()), "aptp_gate_bwd")
-    dgate = part.sum(dim=1).view(B // Bg, Bg, G).sum(dim=0)
+    p.gate, p.gate_B, p.dgate_partial, p.dgate = gate.data_ptr(), Bg, part.data_ptr(), dgate.data_ptr()
+    _lib.check(lib.aptp_gate_bwd(ctypes.byref(p), _stream()), "aptp_gate_bwd")   # (the partials are folded by the same call)
     return dx, dgate
 
 
@@ -728,10 +728,49 @@ def geglu_bwd(hg: torch.Tensor, dout: torch.Tensor, gate: Optional[torch.Tensor]
     p.groups = G
     part = torch.empty(B, lib.aptp_groupnorm_nchunk(HW), G, dtype=torch.float32, device=hg.device)
     p.dgate_partial = part.data_ptr()
+    dgate = None
+    if gate is not None:
+        dgate = torch.empty(Bg, G, dtype=torch.float32, device=hg.device)
+        p.dgate = dgate.data_ptr()
     p.backward = 1
     _lib.check(lib.aptp_geglu(ctypes.byref(p), _stream()), "aptp_geglu(bwd)")
-    dgate = part.sum(dim=1).view(B // Bg, Bg, G).sum(dim=0) if gate is not None else None
     return dhg, dgate
+
+
+def depth_lerp(x_in: torch.Tensor, x_out: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """DepthGate.forward in one launch: (1 - d[b % dB]) * x_in + d[b % dB] * x_out; x_in may be a channel slice of a wider
+    buffer (the un-sliced skip-concat of an up-block resnet, blocks.py:485-495)."""
+    lib = _lib.load()
+    B, HW, C, ldin = _rows(x_in)
+    _, _, _, ldout = _rows(x_out)
+    assert x_in.dtype == torch.bfloat16 and x_out.dtype == torch.bfloat16 and x_in.shape == x_out.shape and x_in.is_cuda
+    d = d.detach().to(dtype=torch.float32).reshape(-1).contiguous()
+    y = torch.empty(x_out.shape, dtype=torch.bfloat16, device=x_out.device)
+    p = DepthLerpParams()
+    p.x_in, p.ld_in, p.x_out, p.ld_out, p.y, p.ld_y = x_in.data_ptr(), ldin, x_out.data_ptr(), ldout, y.data_ptr(), C
+    p.B, p.HW, p.C, p.d, p.d_B, p.backward = B, HW, C, d.data_ptr(), d.numel(), 0
+    _lib.check(lib.aptp_depth_lerp(ctypes.byref(p), _stream()), "aptp_depth_lerp")
+    return y
+
+
+def depth_lerp_bwd(dy: torch.Tensor, x_in: torch.Tensor, x_out: torch.Tensor, d: torch.Tensor):
+    """(d_in, d_out, dd [dB] fp32) of depth_lerp"""
+    lib = _lib.load()
+    B, HW, C, ldin = _rows(x_in)
+    _, _, _, ldout = _rows(x_out)
+    _, _, _, lddy = _rows(dy)
+    d = d.detach().to(dtype=torch.float32).reshape(-1).contiguous()
+    d_in = torch.empty(x_out.shape, dtype=torch.bfloat16, device=dy.device)
+    d_out = torch.empty(x_out.shape, dtype=torch.bfloat16, device=dy.device)
+    part = torch.empty(B, lib.aptp_groupnorm_nchunk(HW), dtype=torch.float32, device=dy.device)
+    dd = torch.empty(d.numel(), dtype=torch.float32, device=dy.device)
+    p = DepthLerpParams()
+    p.x_in, p.ld_in, p.x_out, p.ld_out = x_in.data_ptr(), ldin, x_out.data_ptr(), ldout
+    p.dy, p.ld_dy, p.d_in, p.ld_d_in, p.d_out, p.ld_d_out = dy.data_ptr(), lddy, d_in.data_ptr(), C, d_out.data_ptr(), C
+    p.B, p.HW, p.C, p.d, p.d_B = B, HW, C, d.data_ptr(), d.numel()
+    p.dd_partial, p.dd, p.backward = part.data_ptr(), dd.data_ptr(), 1
+    _lib.check(lib.aptp_depth_lerp(ctypes.byref(p), _stream()), "aptp_depth_lerp(bwd)")
+    return d_in, d_out, dd
 
 
 def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,

@@ -391,7 +391,7 @@ class GraphedPrunerStep(PrunerStep):
         with torch.cuda.graph(g_student, pool=g_teacher.pool()):
             loss, dist, blk, grads = student(full_pred, teacher_acts)
         self._cap = dict(st=st, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, loss=loss, dist=dist, blk=blk,
-                         grads=grads, full_pred=full_pred)
+                         grads=grads, full_pred=full_pred, side=torch.cuda.Stream())
         return self
 
     # ---- one step -------------------------------------------------------------------------------------------------------
@@ -399,6 +399,7 @@ class GraphedPrunerStep(PrunerStep):
         if self._cap is None:
             return super().step(noisy_latents, timesteps, encoder_hidden_states, text_embeddings, target, pretrain)
         cfg, cap = self.cfg, self._cap
+        self._stage_batch_and_launch_teacher(noisy_latents, timesteps, encoder_hidden_states, target)
         arch_vector = self.hyper_net(text_embeddings)
         arch_vector_quantized, _ = self.quantizer(arch_vector)
         arch_vector = self.quantizer.gumbel_sigmoid_trick(arch_vector)
@@ -408,8 +409,12 @@ class GraphedPrunerStep(PrunerStep):
         contrastive_loss = self.contrastive(text_all, arch_all)
         pieces = list(sep["width"]) + list(sep["depth"])
 
+        # The teacher depends on the batch only: its graph replays on a side stream WHILE the router above (hundreds of
+        # launch-bound kernels of a few microseconds each, during which the GPU is mostly idle) is still being issued on
+        # this stream.  Order on the device: batch copies -> [teacher graph || router] -> student graph.
+        # (The copies were queued first thing in this step, see _stage_batch.)
         # MAC accounting is differentiable in the gates (calc_macs family): feed it the router-connected tensors.  Done
-        # BEFORE the replays are queued and without the host classification copy, so the host never waits on the graphs.
+        # BEFORE the student replay is queued and without the host classification copy, so the host never waits on the graphs.
         self.unet.set_structure({"width": list(sep["width"]), "depth": list(sep["depth"])}, prefetch_hosts=False)
         macs = self.unet.calc_macs()
         ratios = macs["cur_prunable_macs"] / self.unet.resource_info_dict["cur_prunable_macs"].squeeze()
@@ -418,13 +423,9 @@ class GraphedPrunerStep(PrunerStep):
         std_loss = -torch.std(ratios)
 
         with torch.no_grad():
-            for k, src in (("noisy_latents", noisy_latents), ("timesteps", timesteps),
-                           ("encoder_hidden_states", encoder_hidden_states), ("target", target)):
-                cap["st"][k].copy_(src)
-            cap["st"]["snr_w"].copy_(self._snr_weights(timesteps))
             for dst, src in zip(cap["gw"] + cap["gd"], pieces):
                 dst.copy_(src.reshape(dst.shape))
-        cap["g_teacher"].replay()
+        torch.cuda.current_stream().wait_stream(cap["side"])          # teacher outputs ready
         cap["g_student"].replay()
 
         router_loss = cfg.resource_weight * resource_loss + cfg.contrastive_weight * contrastive_loss \
@@ -436,6 +437,18 @@ class GraphedPrunerStep(PrunerStep):
                 "contrastive_loss": contrastive_loss.detach(), "resource_loss": resource_loss.detach(),
                 "resource_ratio": ratios.mean().detach(), "arch_vector_quantized": arch_vector_quantized.detach(),
                 "_router_loss": router_loss, "_gate_tensors": pieces, "_gate_grads": gate_grads}
+
+    def _stage_batch_and_launch_teacher(self, noisy_latents, timesteps, encoder_hidden_states, target):
+        cap = self._cap
+        with torch.no_grad():
+            for k, src in (("noisy_latents", noisy_latents), ("timesteps", timesteps),
+                           ("encoder_hidden_states", encoder_hidden_states), ("target", target)):
+                cap["st"][k].copy_(src)
+            cap["st"]["snr_w"].copy_(self._snr_weights(timesteps))
+        side = cap["side"]
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            cap["g_teacher"].replay()
 
     @staticmethod
     def backward(out: dict):

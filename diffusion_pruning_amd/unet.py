@@ -327,7 +327,7 @@ class ResnetBlock2DWidthGated(nn.Module):
             h = AG.GateFn.apply(h, gate.to(device=dev, dtype=torch.float32))
         a2 = AG.GroupNormFn.apply(h, pl["g2"], pl["b2"], self.groups, self.eps, True)
         sc = x if pl["wsc"] is None else AG.conv(x, pl["wsc"], self._bwd_pack(pl, "wsc", self.conv_shortcut.weight if self.conv_shortcut is not None else None, dev), pad=0)
-        out = AG.conv(a2, pl["w2"], self._bwd_pack(pl, "w2", self.conv2.weight, dev)) + sc
+        out = AG.conv(a2, pl["w2"], self._bwd_pack(pl, "w2", self.conv2.weight, dev), residual=sc)
         if self.depth_gated:
             d = self.depth_gate.gate_f
             d_hard, _ = self._depth_state()
@@ -693,7 +693,7 @@ class Transformer2DModelWidthGated(nn.Module):
         qkv = AG.conv(n, pl["a1_qkv"], bwd("a1_qkv", lambda: torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)), pad=0)
         qkv = gated(qkv, a1.gate, 3)
         o = AG.SelfAttnFn.apply(qkv, a1.heads)
-        h = AG.conv(o, pl["a1_o"], bwd("a1_o", lambda: a1.to_out[0].weight), pad=0) + h
+        h = AG.conv(o, pl["a1_o"], bwd("a1_o", lambda: a1.to_out[0].weight), pad=0, residual=h)
         # cross attention
         n = AG.LayerNormFn.apply(h, pl["ln2_g"], pl["ln2_b"], 1e-5)
         a2 = tb.attn2
@@ -704,7 +704,7 @@ class Transformer2DModelWidthGated(nn.Module):
             pl["a2_kv"] = ops.pack_weight(pl["a2_kv_w"], None, device=dev)
         kv = gated(AG.conv(ehs, pl["a2_kv"], None, pad=0), a2.gate, 2)
         o = AG.CrossAttnFn.apply(q, kv, a2.heads)
-        h = AG.conv(o, pl["a2_o"], bwd("a2_o", lambda: a2.to_out[0].weight), pad=0) + h
+        h = AG.conv(o, pl["a2_o"], bwd("a2_o", lambda: a2.to_out[0].weight), pad=0, residual=h)
         # feed-forward (GEGLU in its un-interleaved training form)
         n = AG.LayerNormFn.apply(h, pl["ln3_g"], pl["ln3_b"], 1e-5)
         geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
@@ -715,8 +715,8 @@ class Transformer2DModelWidthGated(nn.Module):
         hu = geglu.gate.hard_uniform()
         ffgate = None if (not fg.requires_grad and hu is not None and bool((hu == 1).all())) else fg.to(device=dev, dtype=torch.float32)
         f = AG.GegluFn.apply(hg, ffgate)
-        h = AG.conv(f, pl["ff2"], bwd("ff2", lambda: lin2.weight), pad=0) + h
-        out = AG.conv(h, pl["proj_out"], bwd("proj_out", lambda: self.proj_out.weight), pad=0) + x_tok
+        h = AG.conv(f, pl["ff2"], bwd("ff2", lambda: lin2.weight), pad=0, residual=h)
+        out = AG.conv(h, pl["proj_out"], bwd("proj_out", lambda: self.proj_out.weight), pad=0, residual=x_tok)
         if self.depth_gated:
             d = self.depth_gate.gate_f
             d_hard, _ = self._depth_state()

@@ -304,6 +304,8 @@ typedef struct {
   int32_t B, HW, C, groups;
   const float* gate; int32_t gate_B;   /* fp32 [gate_B, groups] */
   float* dgate_partial;                /* fp32 [B, nchunk, groups] */
+  float* dgate;                        /* optional fp32 [gate_B, groups]: the partials folded over the chunk axis and over
+                                          the batch rows that share a gate row (b = rep*gate_B + bg), fixed order */
 } AptpGateBwdParams;
 int aptp_gate_bwd(const AptpGateBwdParams* p, aptp_stream_t stream);
 
@@ -318,8 +320,28 @@ typedef struct {
   const float* gate; int32_t gate_B;   /* fp32 [gate_B, groups] or NULL (mask == 1) */
   float* dgate_partial;                /* fp32 [B, nchunk, groups] (backward) */
   int32_t backward;
+  float* dgate;                        /* optional fp32 [gate_B, groups] (backward): folded partials, as in AptpGateBwdParams */
 } AptpGegluParams;
 int aptp_geglu(const AptpGegluParams* p, aptp_stream_t stream);
+
+/* DepthGate in its training form (pdm/models/unet/gates.py:36-42): forward y = (1 - d[b % d_B]) * x_in + d[b % d_B] * x_out;
+ * backward (backward = 1): d_out = dy * d, d_in = dy * (1 - d), dd[bg] = sum over the samples that share gate row bg and over
+ * all elements of dy * (x_out - x_in) (two-stage, deterministic; dd_partial: fp32 [B, aptp_groupnorm_nchunk(HW)] scratch).
+ * In the reference this is five elementwise passes forward and autograd's chain backward; here one launch each way. */
+typedef struct {
+  const void* x_in; int64_t ld_in;     /* bf16 [B*HW, C] */
+  const void* x_out; int64_t ld_out;   /* bf16 [B*HW, C] */
+  void* y; int64_t ld_y;               /* bf16 [B*HW, C]  (forward) */
+  const void* dy; int64_t ld_dy;       /* bf16 [B*HW, C]  (backward) */
+  void* d_in; int64_t ld_d_in;         /* bf16 [B*HW, C]  (backward) */
+  void* d_out; int64_t ld_d_out;       /* bf16 [B*HW, C]  (backward) */
+  int32_t B, HW, C;
+  const float* d; int32_t d_B;         /* fp32 [d_B] */
+  float* dd_partial;                   /* fp32 [B, nchunk] (backward) */
+  float* dd;                           /* fp32 [d_B] (backward) */
+  int32_t backward;
+} AptpDepthLerpParams;
+int aptp_depth_lerp(const AptpDepthLerpParams* p, aptp_stream_t stream);
 
 /* GroupNorm(+SiLU) data gradient.  fwd_stats = the [B, nchunk, groups, 2] (sum, sumsq) partials the forward wrote into its
  * workspace (keep that buffer alive); workspace: fp32 [B, nchunk, groups, 2]. */

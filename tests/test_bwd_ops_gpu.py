@@ -158,3 +158,56 @@ def test_attention_bwd(ops, cuda, case):
     assert rel_l2(dv.float().cpu(), v.grad) <= 1e-2
     assert rel_l2(dq.float().cpu(), q.grad) <= 1.5e-2
     assert rel_l2(dk.float().cpu(), k.grad) <= 1.5e-2
+
+
+@pytest.mark.parametrize("B,dB,HW,C,wide", [(4, 2, 64, 64, 0), (2, 2, 1024, 320, 320), (4, 1, 256, 1280, 1280), (2, 1, 30, 2560, 0)])
+def test_depth_lerp_fwd_bwd(ops, cuda, B, dB, HW, C, wide):
+    """DepthGate in its training form (gates.py:36-42) in one launch each way; x_in may be a channel slice of a wider
+    buffer (ld > C: the un-sliced skip-concat of an up-block resnet); the gate is tiled over the batch (CFG)."""
+    from diffusion_pruning_amd import autograd as AG
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    buf = torch.randn(B, HW, C + wide, generator=g).bfloat16()
+    xo = torch.randn(B, HW, C, generator=g).bfloat16()
+    d = torch.rand(dB, generator=g)
+    dy = torch.randn(B, HW, C, generator=g).bfloat16()
+    xi_ref = buf[..., :C].float().requires_grad_()
+    xo_ref = xo.float().requires_grad_()
+    d_ref = d.clone().requires_grad_()
+    dm = d_ref.repeat(B // dB).view(B, 1, 1)
+    y_ref = (1 - dm) * xi_ref + dm * xo_ref
+    y_ref.backward(dy.float())
+    bufd = buf.to(cuda)
+    xi = bufd[..., :C].requires_grad_()
+    xod = xo.to(cuda).requires_grad_()
+    dd = d.to(cuda).requires_grad_()
+    y = AG.depth_lerp(xi, xod, dd)
+    assert rel_l2(y.float().cpu(), y_ref.detach()) <= 4e-3
+    y.backward(dy.to(cuda))
+    torch.cuda.synchronize()
+    assert rel_l2(xi.grad.float().cpu(), xi_ref.grad) <= 4e-3
+    assert rel_l2(xod.grad.float().cpu(), xo_ref.grad) <= 4e-3
+    assert rel_l2(dd.grad.float().cpu(), d_ref.grad) <= 1e-3
+    # deterministic two-stage reduction: a second backward gives bit-identical gate gradients
+    d2 = d.to(cuda).requires_grad_()
+    AG.depth_lerp(bufd[..., :C], xo.to(cuda), d2).backward(dy.to(cuda))
+    assert torch.equal(d2.grad, dd.grad)
+
+
+def test_conv_with_fused_residual_matches_separate_add(ops, cuda):
+    """AG.conv(residual=): the residual add runs in the GEMM epilogue, its gradient is dy itself"""
+    from diffusion_pruning_amd import autograd as AG
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 320, generator=g).bfloat16().to(cuda).requires_grad_()
+    r = torch.randn(2, 64, 640, generator=g).bfloat16().to(cuda).requires_grad_()
+    w = (torch.randn(640, 320, generator=g) / 18).to(cuda)
+    pw = ops.pack_weight(w, torch.zeros(640), device=cuda)
+    get = lambda: ops.pack_weight_dgrad(w, device=cuda)
+    dy = torch.randn(2, 64, 640, generator=g).bfloat16().to(cuda)
+    y = AG.conv(x, pw, get, pad=0, residual=r)
+    y.backward(dy)
+    gx, gr = x.grad.clone(), r.grad.clone()
+    x.grad = r.grad = None
+    y2 = AG.conv(x, pw, get, pad=0) + r
+    y2.backward(dy)
+    assert rel_l2(y.float(), y2.float()) <= 4e-3                 # one bf16 rounding instead of two
+    assert torch.equal(gx, x.grad) and torch.equal(gr, r.grad)

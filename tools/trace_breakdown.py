@@ -31,12 +31,17 @@ def main(path, skip_tail=0):
     # kernel that runs once per forward (the U-Net prologue / timestep sinusoid) and take the last three equal-length periods
     marks = [i for i, nm in enumerate(names) if "unet_prologue_kernel" in nm or "sin_kernel" in nm]
     if len(marks) >= 4 and (best is None or best < 100):
-        for j in range(len(marks) - 1, 2, -1):
-            p = marks[j] - marks[j - 1]
-            if p >= 100 and marks[j - 1] - marks[j - 2] == p and marks[j - 2] - marks[j - 3] == p \
-                    and names[marks[j - 1]:marks[j]] == names[marks[j - 2]:marks[j - 1]]:
-                best, n = p, marks[j]
-                rows = rows[:n]
+        done = False
+        for stride in (1, 2):           # 2: a train step runs the U-Net prologue twice (teacher, student)
+            for j in range(len(marks) - 1, 3 * stride - 1, -1):
+                p = marks[j] - marks[j - stride]
+                if p >= 100 and marks[j - stride] - marks[j - 2 * stride] == p and marks[j - 2 * stride] - marks[j - 3 * stride] == p \
+                        and names[marks[j - stride]:marks[j]] == names[marks[j - 2 * stride]:marks[j - stride]]:
+                    best, n = p, marks[j]
+                    rows = rows[:n]
+                    done = True
+                    break
+            if done:
                 break
     if best is None:
         print("no periodic tail found")

@@ -113,6 +113,14 @@ class GegluParams(Structure):
     ]
 
 
+class WgradParams(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dw", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("N", c_int32), ("KH", c_int32), ("KW", c_int32),
+        ("split_m", c_int32),
+    ]
+
+
 class DepthLerpParams(Structure):
     _fields_ = [
         ("x_in", c_void_p), ("ld_in", c_int64), ("x_out", c_void_p), ("ld_out", c_int64), ("y", c_void_p), ("ld_y", c_int64),
@@ -204,6 +212,9 @@ EXPORTS = [
     ("aptp_gate_bwd", c_int, [POINTER(GateBwdParams), c_void_p]),
     ("aptp_geglu", c_int, [POINTER(GegluParams), c_void_p]),
     ("aptp_depth_lerp", c_int, [POINTER(DepthLerpParams), c_void_p]),
+    ("aptp_conv_wgrad_supported", c_int, [POINTER(WgradParams)]),
+    ("aptp_conv_wgrad_suggest_split", c_int, [POINTER(WgradParams)]),
+    ("aptp_conv_wgrad", c_int, [POINTER(WgradParams), c_void_p]),
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),
     ("aptp_layernorm_bwd", c_int, [POINTER(LayerNormBwdParams), c_void_p]),
     ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),

@@ -75,7 +75,7 @@ class GateFn(Function):
     @staticmethod
     def forward(ctx, y0, gate):
         y0 = _c(y0)
-        y1, _ = ops.gate_bwd(y0, y0, gate)      # the backward kernel's dx = dy*gate path with dy := y0
+        y1, _ = ops.gate_bwd(y0, y0, gate, want_dgate=False)      # the backward kernel's dx = dy*gate path with dy := y0
         ctx.save_for_backward(y0, gate)
         return y1
 

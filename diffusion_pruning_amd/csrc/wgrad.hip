@@ -1,0 +1,207 @@
+// Weight gradient of a stride-1 "same" convolution (3x3 or 1x1 / linear) for the expert fine-tune step (SURVEY a20,
+// trainer.py:1616 loss.backward through F.conv2d / F.linear): dW[n][tap][c] = sum_m dy[m][n] * x[pix(m, tap)][c].
+//
+// The contraction runs over PIXELS, and both operands are stored pixel-major (channels contiguous), so the MFMA's K
+// dimension is the strided one.  gfx950's transposed LDS read (ds_read_b64_tr_b16: a 4-row x 16-column block delivered
+// column-major) makes that free: the tiles are copied to LDS exactly as they lie in memory ([pixel][channel], 16-byte
+// chunks) and read back K-major.  No im2col, no transposed copies of dy or x in HBM.
+//
+// Workgroup = one (64 output channels n) x (64 input channels c) block of dW for ALL taps and one slice of the pixel range.
+// Per 32-pixel K-step it stages the dy tile [32][64] and, for a 3x3 filter, the input HALO of those 32 pixels
+// ((R+2) x (Wt+2) pixels, R = rows covered, Wt = min(W, 32)) once; the nine taps are nine shifted row offsets into that
+// one LDS image (the shift is in the pixel dimension, where a transposed read takes any row address), so x is read 1.06x
+// instead of 9x and dy once.  4 waves as 2(n) x 2(c), wave tile 32 x 32, mfma_f32_16x16x32_bf16 with A = x^T fragment
+// (rows = c), B = dy^T fragment (columns = n): a lane ends up with 4 consecutive c of one n -> 16-byte stores into the
+// packed-weight order [n][tap][c].  Global loads of step s+1 are in flight during the MFMAs of step s (register staging,
+// two LDS buffers, one barrier per step).  The pixel range is split over `split_m` workgroups (fp32 slabs, summed by the
+// caller in a fixed order: deterministic).
+#include "aptp_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct WgK {
+  const __bf16* x; int64_t ldx; const __bf16* dy; int64_t lddy; float* dw;
+  int B, H, W, C, N, M, HW, split, nsteps, tiles_n, tiles_c;
+  int Wt, R, hw2;      // halo geometry (3x3): tile width, rows per step, Wt + 2
+};
+
+constexpr int PITCH = 72;          // bf16 elements per LDS row (64 + 8: spreads the 4-row transposed blocks over the banks)
+constexpr int XROWS = 104;         // halo rows per buffer: (R+2) * (Wt+2) <= 102
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* lds_row_q_col_4p, int plus4_rows_elems) {
+  // two 4-row x 16-column transposed blocks -> the 8 consecutive k of one MFMA operand lane
+  typedef __attribute__((address_space(3))) s16x4* lp;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_row_q_col_4p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_row_q_col_4p + plus4_rows_elems));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
+  __shared__ __attribute__((aligned(16))) __bf16 dys[2][32 * PITCH];
+  __shared__ __attribute__((aligned(16))) __bf16 xs[2][(TAPS == 9 ? XROWS : 32) * PITCH];
+  constexpr int XCH = TAPS == 9 ? 4 : 1;           // 16-byte x chunks per thread and step (<= 102 * 8 / 256)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1;
+  int bid = blockIdx.x;
+  const int slice = bid % p.split; bid /= p.split;
+  const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
+  const int n0 = tn * 64, c0 = tc * 64;
+  const int s_begin = (int)(((int64_t)p.nsteps * slice) / p.split), s_end = (int)(((int64_t)p.nsteps * (slice + 1)) / p.split);
+
+  // ---- staging registers -------------------------------------------------------------------------------------------------
+  u32x4 rdy, rx[XCH];
+  const int dj = tid >> 3, dch = tid & 7;          // dy tile: row (pixel of the step), 16-byte chunk
+  const int xrows = TAPS == 9 ? (p.R + 2) * p.hw2 : 32;
+  auto load_step = [&](int step) {
+    const int m0 = step * 32;
+    {
+      const int m = m0 + dj, n = n0 + dch * 8;
+      rdy = (u32x4){0u, 0u, 0u, 0u};
+      if (m < p.M && n < p.N) rdy = *reinterpret_cast<const u32x4*>(p.dy + (int64_t)m * p.lddy + n);
+    }
+    if (TAPS == 9) {
+      const int b = m0 / p.HW, rem = m0 - b * p.HW;
+      const int y0 = rem / p.W, x0 = rem - y0 * p.W;
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int id = tid + 256 * i, hr = id >> 3, ch = id & 7;
+        rx[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (hr < xrows) {
+          const int hy = hr / p.hw2, hx = hr - hy * p.hw2;
+          const int iy = y0 - 1 + hy, ix = x0 - 1 + hx, c = c0 + ch * 8;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.C)
+            rx[i] = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)(b * p.H + iy) * p.W + ix) * p.ldx + c);
+        }
+      }
+    } else {
+      const int m = m0 + dj, c = c0 + dch * 8;
+      rx[0] = (u32x4){0u, 0u, 0u, 0u};
+      if (m < p.M && c < p.C) rx[0] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * p.ldx + c);
+    }
+  };
+  auto store_step = [&](int buf) {
+    *reinterpret_cast<u32x4*>(&dys[buf][dj * PITCH + dch * 8]) = rdy;
+    if (TAPS == 9) {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int id = tid + 256 * i, hr = id >> 3, ch = id & 7;
+        if (hr < xrows) *reinterpret_cast<u32x4*>(&xs[buf][hr * PITCH + ch * 8]) = rx[i];
+      }
+    } else {
+      *reinterpret_cast<u32x4*>(&xs[buf][dj * PITCH + dch * 8]) = rx[0];
+    }
+  };
+
+  // ---- fragment addressing (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3) -------------
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int j = 8 * g + q;                                   // pixel of the step this lane addresses (and j + 4)
+  int xrow = j;                                              // its row in the x image for tap (0, 0)
+  if (TAPS == 9) xrow = (j / p.Wt) * p.hw2 + (j % p.Wt);    // (halo coordinates of the pixel's top-left neighbour)
+  const int x_off = xrow * PITCH + wc * 32 + 4 * pp;         // + cf*16 + tap shift * PITCH
+  const int d_off = j * PITCH + wn * 32 + 4 * pp;            // + nf*16
+
+  f32x4 acc[TAPS][2][2];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) acc[t][a][b2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (s_begin < s_end) {
+    load_step(s_begin);
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      store_step(buf);
+      __syncthreads();
+      if (s + 1 < s_end) load_step(s + 1);
+      bf16x8 dfr[2];
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) dfr[nf] = tr_frag(&dys[buf][d_off + nf * 16], 4 * PITCH);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int shift = TAPS == 9 ? ((t / 3) * p.hw2 + (t % 3)) * PITCH : 0;
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) {
+          const bf16x8 xf = tr_frag(&xs[buf][x_off + shift + cf * 16], 4 * PITCH);
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf)
+            acc[t][cf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, dfr[nf], acc[t][cf][nf], 0, 0, 0);
+        }
+      }
+      buf ^= 1;
+    }
+  }
+
+  // ---- store: lane owns c = cbase + 4*(lane/16) .. +3 of n = nbase + lane%16 -------------------------------------------------
+  float* out = p.dw + (int64_t)slice * p.N * TAPS * p.C;
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+    const int n = n0 + wn * 32 + nf * 16 + (lane & 15);
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+      const int c = c0 + wc * 32 + cf * 16 + 4 * (lane >> 4);
+      if (c >= p.C) continue;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        float4 o; o.x = acc[t][cf][nf][0]; o.y = acc[t][cf][nf][1]; o.z = acc[t][cf][nf][2]; o.w = acc[t][cf][nf][3];
+        *reinterpret_cast<float4*>(out + ((int64_t)n * TAPS + t) * p.C + c) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+#define ALIGN16(p) (((uintptr_t)(p) % 16) == 0)
+
+extern "C" int aptp_conv_wgrad_supported(const AptpWgradParams* p) {
+  if (!p || (p->KH != 1 && p->KH != 3) || p->KH != p->KW) return 0;
+  if (p->C % 8 || p->N % 8 || p->ldx % 8 || p->lddy % 8) return 0;
+  if (p->KH == 3) {
+    const int W = p->W, HW = p->H * p->W;
+    if (HW % 32) return 0;
+    if (!((W >= 32 && W % 32 == 0) || (W >= 8 && 32 % W == 0))) return 0;
+  }
+  return 1;
+}
+
+extern "C" int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p) {
+  const int M = p->B * p->H * p->W, nsteps = (M + 31) / 32;
+  const int tiles = ((p->N + 63) / 64) * ((p->C + 63) / 64);
+  int split = (512 + tiles - 1) / tiles;
+  const int cap = nsteps / 4 > 0 ? nsteps / 4 : 1;
+  split = split < 1 ? 1 : (split > cap ? cap : split);
+  return split > 64 ? 64 : split;
+}
+
+extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->x && p->dy && p->dw, "conv_wgrad: null pointer");
+  APTP_CHECK(aptp_conv_wgrad_supported(p), "conv_wgrad: unsupported geometry (KH=%d KW=%d H=%d W=%d C=%d N=%d)", p->KH, p->KW, p->H, p->W, p->C, p->N);
+  APTP_CHECK(ALIGN16(p->x) && ALIGN16(p->dy) && ALIGN16(p->dw) && p->split_m >= 1, "conv_wgrad: alignment / split");
+  WgK k;
+  k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dw = p->dw;
+  k.B = p->B; k.H = p->H; k.W = p->W; k.C = p->C; k.N = p->N; k.HW = p->H * p->W; k.M = p->B * k.HW;
+  k.nsteps = (k.M + 31) / 32;
+  k.split = p->split_m > k.nsteps ? k.nsteps : p->split_m;
+  APTP_CHECK(k.split == p->split_m, "conv_wgrad: split_m %d exceeds the %d K-steps", p->split_m, k.nsteps);
+  k.tiles_n = (p->N + 63) / 64; k.tiles_c = (p->C + 63) / 64;
+  k.Wt = p->W < 32 ? p->W : 32; k.R = p->W < 32 ? 32 / p->W : 1; k.hw2 = k.Wt + 2;
+  APTP_CHECK(p->KH == 1 || (k.R + 2) * k.hw2 <= XROWS, "conv_wgrad: halo does not fit");
+  const int64_t nblk = (int64_t)k.tiles_n * k.tiles_c * k.split;
+  APTP_CHECK(nblk < (1LL << 31), "conv_wgrad: grid too large");
+  if (p->KH == 3) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import UnetEpilogueParams, UnetPrologueParams
-from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams,
+from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams, WgradParams,
                    GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
                    ColsumParams, LayerNormPgradParams)
 
@@ -674,8 +674,9 @@ def _rows(t: torch.Tensor):
     return B, L, C, (t.stride(1) if L > 1 else max(t.stride(1), C))
 
 
-def gate_bwd(dy: torch.Tensor, y0: torch.Tensor, gate: torch.Tensor):
-    """dx = dy * gate (expanded over channel groups, batch tiled), dgate [Bg, G] = sum dy*y0 (fp32)."""
+def gate_bwd(dy: torch.Tensor, y0: torch.Tensor, gate: torch.Tensor, want_dgate: bool = True):
+    """dx = dy * gate (expanded over channel groups, batch tiled), dgate [Bg, G] = sum dy*y0 (fp32).
+    want_dgate=False: the forward gate multiply (dy := y0) -- the partials are not folded, dgate is None."""
     lib = _lib.load()
     B, HW, C, lddy = _rows(dy)
     _, _, _, ldy0 = _rows(y0)
@@ -685,11 +686,11 @@ def gate_bwd(dy: torch.Tensor, y0: torch.Tensor, gate: torch.Tensor):
     dx = torch.empty_like(dy, memory_format=torch.contiguous_format)
     nchunk = lib.aptp_groupnorm_nchunk(HW)
     part = torch.empty(B, nchunk, G, dtype=torch.float32, device=dy.device)
-    dgate = torch.empty(Bg, G, dtype=torch.float32, device=dy.device)
+    dgate = torch.empty(Bg, G, dtype=torch.float32, device=dy.device) if want_dgate else None
     p = GateBwdParams()
     p.dy, p.lddy, p.y0, p.ldy0, p.dx, p.lddx = dy.data_ptr(), lddy, y0.data_ptr(), ldy0, dx.data_ptr(), C
     p.B, p.HW, p.C, p.groups = B, HW, C, G
-    p.gate, p.gate_B, p.dgate_partial, p.dgate = gate.data_ptr(), Bg, part.data_ptr(), dgate.data_ptr()
+    p.gate, p.gate_B, p.dgate_partial, p.dgate = gate.data_ptr(), Bg, part.data_ptr(), (dgate.data_ptr() if want_dgate else None)
     _lib.check(lib.aptp_gate_bwd(ctypes.byref(p), _stream()), "aptp_gate_bwd")   # (the partials are folded by the same call)
     return dx, dgate
 
@@ -861,10 +862,35 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional
 
 # ------------------------------------------------------------------------------------------------------------------
 # weight gradients (expert fine-tuning): dW[n, tap, c] = sum_m dy[m, n] * x[pix(m, tap), c]
-# The reduction runs over pixels, so both operands are presented K-major (transposed) to the SAME implicit-GEMM kernel:
-# "activations" = dy^T [N rows, M], "weights" = im2col(x)^T [taps*C rows, M]; split-K spreads the long reduction over
-# the chip.  The transposes / im2col are data-movement glue (strided copies); the contraction is aptp_conv_gemm.
+# Stride-1 3x3 / 1x1 / linear layers (all but the six down/up-sampler convolutions of SD-2.1) run aptp_conv_wgrad: the
+# operands stay in their forward layout and the kernel reads its LDS tiles K-major (transposed LDS reads), one input halo
+# per 32-pixel step serving all nine taps.  The remaining geometries fall back to the implicit-GEMM kernel on transposed
+# copies ("activations" = dy^T, "weights" = im2col(x)^T; the copies are torch strided copies).
+# WGRAD_KERNEL=False forces the fallback everywhere (A/B timing, tests of both forms).
 # ------------------------------------------------------------------------------------------------------------------
+WGRAD_KERNEL = os.environ.get("APTP_WGRAD_KERNEL", "1") != "0"
+
+
+def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: Optional[int] = None):
+    """x [B,H,W,C], dy [B,H,W,N] (bf16, channels contiguous, uniform pixel stride) -> fp32 [N, KH*KW, C] or None when
+    the geometry is not handled by aptp_conv_wgrad"""
+    lib = _lib.load()
+    B, H, W, C = x.shape
+    N = dy.shape[3]
+    p = WgradParams()
+    p.x, p.ldx, p.dy, p.lddy = x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy)
+    p.B, p.H, p.W, p.C, p.N, p.KH, p.KW = B, H, W, C, N, KH, KW
+    if x.data_ptr() % 16 or dy.data_ptr() % 16 or not lib.aptp_conv_wgrad_supported(ctypes.byref(p)):
+        return None
+    _check_act(x, "conv_wgrad x")
+    _check_act(dy, "conv_wgrad dy")
+    p.split_m = int(split_m) if split_m else lib.aptp_conv_wgrad_suggest_split(ctypes.byref(p))
+    slabs = torch.empty(p.split_m, N, KH * KW, C, dtype=torch.float32, device=x.device)
+    p.dw = slabs.data_ptr()
+    _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
+    return slabs[0] if p.split_m == 1 else slabs.sum(dim=0)
+
+
 def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int) -> torch.Tensor:
     """x [B,H,W,C] bf16 -> [KH*KW*C, M] (M = B*Hout*Wout), taps-major then channels, matching the packed weight order."""
     B, H, W, C = x.shape
@@ -888,8 +914,13 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     """Weight gradient of y = conv(x, w): returns fp32 [N, KH*KW, C] (the packed-weight order, unpadded).
     x [B,H,W,C] (or tokens [B,L,C] with KH=KW=1), dy [B,Ho,Wo,N] (or [B,L,N]); both bf16."""
     if x.dim() == 3:
-        x, dy = x.unsqueeze(2), dy.unsqueeze(2)
+        # tokens: one image of B*L x 1 "pixels" (a linear layer has no spatial structure)
+        x, dy = x.reshape(1, -1, 1, x.shape[-1]), dy.reshape(1, -1, 1, dy.shape[-1])
     C, N = x.shape[-1], dy.shape[-1]
+    if WGRAD_KERNEL and stride == 1 and ups == 0 and KH == KW and pad == KH // 2 and x.shape[:3] == dy.shape[:3]:
+        g = _wgrad_direct(x, dy, KH, KW)
+        if g is not None:
+            return g
     xt = _im2col_T(x, KH, KW, stride, pad, ups)                   # [K, M]
     K, M = xt.shape
     dyt = dy.reshape(M, N).t().contiguous()                         # [N, M]

@@ -343,6 +343,23 @@ typedef struct {
 } AptpDepthLerpParams;
 int aptp_depth_lerp(const AptpDepthLerpParams* p, aptp_stream_t stream);
 
+/* Weight gradient of a stride-1 "same" convolution (3x3, pad 1) or of a 1x1 convolution / linear layer, for the expert
+ * fine-tune step (pdm/training/trainer.py:1616, loss.backward through F.conv2d / F.linear of the pruned expert):
+ *   dw[s][n][tap][c] = sum over the pixels m of slice s of dy[m][n] * x[pix(m, tap)][c]      (fp32, packed-weight order)
+ * The caller sums the split_m slabs (fixed order: deterministic).  Operands stay in their forward layout: no im2col and no
+ * transposed copies; the kernel reads its LDS tiles K-major with gfx950's transposed LDS read.
+ * aptp_conv_wgrad_supported: 1 when the geometry is handled (KH == KW in {1, 3}; C, N, ld multiples of 8; for 3x3: H*W a
+ * multiple of 32 and W a multiple of 32 or a divisor of 32 that is >= 8), else 0 (use the GEMM on transposed copies). */
+typedef struct {
+  const void* x; int64_t ldx;      /* bf16 [B*H*W, C]: the convolution's input */
+  const void* dy; int64_t lddy;    /* bf16 [B*H*W, N]: gradient of its output */
+  float* dw;                       /* fp32 [split_m, N, KH*KW, C] */
+  int32_t B, H, W, C, N, KH, KW, split_m;
+} AptpWgradParams;
+int aptp_conv_wgrad_supported(const AptpWgradParams* p);
+int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p);
+int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream);
+
 /* GroupNorm(+SiLU) data gradient.  fwd_stats = the [B, nchunk, groups, 2] (sum, sumsq) partials the forward wrote into its
  * workspace (keep that buffer alive); workspace: fp32 [B, nchunk, groups, 2]. */
 typedef struct {

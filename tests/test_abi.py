@@ -45,7 +45,8 @@ def test_ctypes_layout_matches_the_c_header():
                "AptpGateBwdParams": _lib.GateBwdParams, "AptpGegluParams": _lib.GegluParams,
                "AptpGroupNormBwdParams": _lib.GroupNormBwdParams, "AptpLayerNormBwdParams": _lib.LayerNormBwdParams,
                "AptpAttentionBwdParams": _lib.AttentionBwdParams, "AptpColsumParams": _lib.ColsumParams,
-               "AptpLayerNormPgradParams": _lib.LayerNormPgradParams, "AptpDepthLerpParams": _lib.DepthLerpParams}
+               "AptpLayerNormPgradParams": _lib.LayerNormPgradParams, "AptpDepthLerpParams": _lib.DepthLerpParams,
+               "AptpWgradParams": _lib.WgradParams}
     body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, cls in structs.items():
         body.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -211,3 +211,56 @@ def test_conv_with_fused_residual_matches_separate_add(ops, cuda):
     y2.backward(dy)
     assert rel_l2(y.float(), y2.float()) <= 4e-3                 # one bf16 rounding instead of two
     assert torch.equal(gx, x.grad) and torch.equal(gr, r.grad)
+
+
+WGRAD_CASES = [  # (B, H, W, C, N, k)
+    (2, 64, 64, 64, 64, 3),      # W = 64: two 32-pixel steps per image row
+    (1, 32, 32, 320, 160, 3),    # W = 32, ragged tiles (C = 5 x 64, N = 2.5 x 64)
+    (2, 16, 16, 128, 200, 3),    # W = 16: a step covers two image rows; N not a multiple of 64
+    (4, 8, 8, 72, 64, 3),        # W = 8: four rows per step; C = 72 (a compacted width)
+    (2, 32, 32, 320, 320, 1),    # 1x1 convolution
+    (1, 308, 1, 1024, 136, 1),   # linear layer over 4 x 77 text tokens: ragged pixel count (308 = 9 x 32 + 20)
+    (1, 4, 1, 320, 1280, 1),     # the time-embedding MLP: 4 rows
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+@pytest.mark.parametrize("split", [None, 1, 3])
+def test_conv_wgrad_kernel(ops, cuda, case, split):
+    """aptp_conv_wgrad (transposed LDS reads, one halo per step for all nine taps) vs PyTorch's weight gradient of the same
+    convolution on the same bf16-rounded operands; also against the GEMM-on-transposed-copies fallback."""
+    B, H, W, C, N, k = case
+    g = torch.Generator().manual_seed(B * 7919 + H * 131 + C + N + k)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = torch.zeros(N, C, k, k, requires_grad=True)
+    dy = torch.randn(B, N, H, W, generator=g).bfloat16().float()
+    F.conv2d(x, w, None, stride=1, padding=k // 2).backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(N, k * k, C)                    # [N, taps, C]: the packed-weight order
+    xd, dyd = nhwc(x).to(cuda).bfloat16(), nhwc(dy).to(cuda).bfloat16()
+    nsteps = (B * H * W + 31) // 32
+    if split is not None and split > nsteps:
+        pytest.skip("more slices than K-steps")
+    got = ops._wgrad_direct(xd, dyd, k, k, split_m=split)
+    assert got is not None, "geometry must be handled by the kernel"
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (N, k * k, C)
+    assert rel_l2(got.float().cpu(), ref) <= 2e-3                           # fp32 accumulation of bf16 products
+    if split is None:
+        ops.WGRAD_KERNEL = False
+        try:
+            old = ops.conv_wgrad(xd, dyd, k, k, 1, k // 2, 0)
+        finally:
+            ops.WGRAD_KERNEL = True
+        assert rel_l2(got.float().cpu(), old.float().cpu()) <= 2e-3
+        assert torch.equal(got, ops._wgrad_direct(xd, dyd, k, k))            # deterministic
+
+
+def test_conv_wgrad_reads_channel_slices_in_place(ops, cuda):
+    """x is a channel slice of a wider buffer (ld > C), as the skip-concat halves are"""
+    g = torch.Generator().manual_seed(5)
+    wide = torch.randn(2, 16, 16, 192, generator=g).bfloat16().to(cuda)
+    x = wide[..., 64:128]
+    dy = torch.randn(2, 16, 16, 64, generator=g).bfloat16().to(cuda)
+    got = ops._wgrad_direct(x, dy, 3, 3)
+    ref = ops._wgrad_direct(x.contiguous(), dy, 3, 3)
+    assert torch.equal(got, ref)

@@ -274,6 +274,57 @@ def conv_w(x, wparam, bparam, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=Fa
     return ConvWFn.apply(x, wparam, bparam, pw, get_bwd, stride, pad, ups, out_f32, live_out, live_in)
 
 
+class ConvPFn(Function):
+    """Packed-parameter form (packed_train.py): the trainable weight is the fp32 tensor ``P`` in the kernels' own order
+    [N][taps][cin_pad]; ``pw`` is its bf16 shadow.  dW comes out of the weight-gradient kernel in that order: no scatter."""
+
+    @staticmethod
+    def forward(ctx, x, P, Pb, pw: PackedWeight, get_bwd, stride: int, pad: int, ups: int, out_f32: bool, residual):
+        tokens = x.dim() == 3
+        xin = x.unsqueeze(2) if tokens else x
+        res = None
+        if residual is not None:
+            res = residual.unsqueeze(2) if tokens else residual
+        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=res)
+        ctx.save_for_backward(x)
+        ctx.meta = (pw, get_bwd, stride, pad, ups, tokens, tuple(P.shape), Pb is not None)
+        return y.squeeze(2) if tokens else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        pw, get_bwd, stride, pad, ups, tokens, pshape, has_bias = ctx.meta
+        dy = _c(dy.to(torch.bfloat16))
+        dx = dP = db = None
+        k = pw.KH
+        if ctx.needs_input_grad[0]:
+            dy4 = dy.unsqueeze(2) if tokens else dy
+            pwb = get_bwd()
+            if stride == 2:
+                dx = ops.conv_gemm(dy4, pwb, stride=1, pad=k - 1 - pad, ups=2)
+            else:
+                dx = ops.conv_gemm(dy4, pwb, stride=1, pad=k - 1 - pad)
+                if ups == 1:
+                    B, H2, W2, C = dx.shape
+                    dx = dx.view(B, H2 // 2, 2, W2 // 2, 2, C).float().sum(dim=(2, 4)).to(torch.bfloat16)
+            dx = dx.squeeze(2) if tokens else dx
+        if ctx.needs_input_grad[1]:
+            g = ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups)            # [N, taps, Cx] fp32
+            if tuple(g.shape) == pshape:
+                dP = g
+            else:
+                dP = torch.zeros(pshape, dtype=torch.float32, device=g.device)
+                dP[:g.shape[0], :, :g.shape[2]] = g
+        if has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy)[:pshape[0]]
+        return dx, dP, db, None, None, None, None, None, None, (dy if ctx.needs_input_grad[9] else None)
+
+
+def conv_p(x, P, Pb, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, residual=None):
+    pad = pw.KH // 2 if pad is None else pad
+    return ConvPFn.apply(x, P, Pb, pw, get_bwd, stride, pad, ups, out_f32, residual)
+
+
 class GroupNormWFn(Function):
     """GroupNorm(+SiLU) with trainable affine; `live` = channel indices of a compacted tensor (norm2 of a pruned resnet)."""
 

@@ -1,0 +1,206 @@
+"""Packed-parameter training of a pruned expert (BASELINE configs[4]; the counterpart of FineTuner's
+optimizer state, pdm/training/trainer.py:1529-1540).
+
+MI355X-first: during fine-tuning the trainable state lives in the KERNELS' layout.  For every contraction of the expert the
+optimizer owns one fp32 tensor in the packed order ``[N][taps][cin_pad]`` -- compact: only the live rows / columns of the
+architecture code -- and the bf16 operand the kernels read is its shadow:
+
+  * the weight-gradient kernel (aptp_conv_wgrad) already produces ``[N][taps][C]``: the gradient needs no scatter into a
+    full-shape OIHW tensor (three full-size passes per weight in the diffusers layout);
+  * after ``optimizer.step()`` the shadows are refreshed with ONE multi-tensor cast (``torch._foreach_copy_``) plus one
+    strided copy per data-gradient operand (the 180-degree-rotated transpose), instead of re-packing every weight from a
+    diffusers-layout master (gather + permute + cast + pad: ~10 launches per weight, ~7,000 per step);
+  * dead channels / heads / FF chunks / dropped blocks carry no optimizer state at all;
+  * nothing in the step depends on the host, so forward + backward + optimizer + refresh replay from one HIP graph
+    (train_step.GraphedFineTunerStep).
+
+Biases and norm affine parameters are compact fp32 tensors that the kernels read directly (no shadow).  The diffusers-named
+full-shape parameters stay the checkpoint interface: ``export_()`` writes the packed values back into them.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import autograd as AG
+from . import ops
+
+
+class _Gemm:
+    """one contraction: packed fp32 master ``P`` [N, taps, cin_pad], optional compact bias ``Pb`` [N] (aliased by the pack),
+    bf16 shadow ``pw`` (forward operand) and ``pwb`` (data-gradient operand, built on first use)"""
+
+    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], pw: ops.PackedWeight,
+                 lo: Optional[torch.Tensor], li: Optional[torch.Tensor]):
+        assert not pw.geglu and pw.ln_colsum is None and pw.Cin2 == 0, "packed training uses the plain packs of the ft path"
+        self.weight, self.bias, self.pw, self.lo, self.li = weight, bias, pw, lo, li
+        dev = pw.w.device
+        w = weight.detach().to(device=dev, dtype=torch.float32)
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        if lo is not None:
+            w = w[lo.to(dev)]
+        if li is not None:
+            w = w[:, li.to(dev)]
+        self.n_live, self.c_live, self.KH, self.KW = w.shape
+        assert self.n_live <= pw.N and self.c_live <= pw.Cin and (self.KH, self.KW) == (pw.KH, pw.KW)
+        P = torch.zeros(pw.w.shape, dtype=torch.float32, device=dev)
+        P[:self.n_live, :, :self.c_live] = w.permute(0, 2, 3, 1).reshape(self.n_live, self.KH * self.KW, self.c_live)
+        self.P = nn.Parameter(P)
+        self.Pb = None
+        if pw.bias is not None:
+            # the pack's fp32 bias becomes the trainable tensor, read directly by the kernels (a fresh tensor: an un-gathered
+            # pack bias can alias the diffusers-layout master, whose storage and version counter must stay untouched)
+            self.Pb = nn.Parameter(pw.bias.detach().clone())
+            pw.bias = self.Pb.data
+        pw.w.copy_(P)                                  # shadow = bf16(master), exactly what a re-pack would give
+        self.pwb: Optional[ops.PackedWeight] = None
+
+    def get_bwd(self) -> ops.PackedWeight:
+        if self.pwb is None:
+            w4 = self.P.detach()[:, :, :self.pw.Cin].reshape(self.pw.N, self.KH, self.KW, self.pw.Cin).permute(0, 3, 1, 2)
+            self.pwb = ops.pack_weight_dgrad(w4, device=self.P.device)
+        return self.pwb
+
+    def refresh_bwd_(self):
+        if self.pwb is not None:
+            N, C = self.pw.N, self.pw.Cin
+            self.pwb.w[:C, :, :N].copy_(self.pw.w[:, :, :C].flip(1).permute(2, 1, 0))
+
+    @torch.no_grad()
+    def export_(self):
+        g = self.P.detach()[:self.n_live, :, :self.c_live].permute(0, 2, 1).reshape(self.n_live, self.c_live, self.KH, self.KW)
+        full = self.weight.data
+        g = g.to(device=full.device, dtype=full.dtype)
+        if full.dim() == 2:
+            g = g.reshape(self.n_live, self.c_live)
+        ro = self.lo.to(full.device) if self.lo is not None else torch.arange(full.shape[0], device=full.device)
+        ci = self.li.to(full.device) if self.li is not None else torch.arange(full.shape[1], device=full.device)
+        full[ro[:, None], ci[None, :]] = g
+        if self.bias is not None and self.Pb is not None:
+            b = self.Pb.detach()[:self.n_live].to(device=self.bias.device, dtype=self.bias.dtype)
+            if self.lo is not None:
+                self.bias.data[self.lo.to(self.bias.device)] = b
+            else:
+                self.bias.data.copy_(b)
+
+
+class _Affine:
+    """compact fp32 (gamma, beta) of a GroupNorm / LayerNorm, read directly by the kernels"""
+
+    def __init__(self, gamma_p: nn.Parameter, beta_p: nn.Parameter, gamma: torch.Tensor, beta: torch.Tensor,
+                 live: Optional[torch.Tensor]):
+        self.gamma_p, self.beta_p, self.live = gamma_p, beta_p, live
+        self.Pg, self.Pb = nn.Parameter(gamma.detach().float().clone()), nn.Parameter(beta.detach().float().clone())
+
+    @torch.no_grad()
+    def export_(self):
+        for P, full in ((self.Pg, self.gamma_p), (self.Pb, self.beta_p)):
+            v = P.detach().to(device=full.device, dtype=full.dtype)
+            if self.live is not None:
+                full.data[self.live.to(full.device)] = v
+            else:
+                full.data.copy_(v)
+
+
+class PackedTrainer:
+    """Registry of the packed trainable state of one expert.  ``attach`` switches the model's fine-tuning forward to it;
+    entries are created the first time a module runs (call ``materialize`` with one batch before building the optimizer)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.gemms: Dict[int, _Gemm] = {}
+        self.affines: Dict[int, _Affine] = {}
+
+    def attach(self):
+        for m in self.model.modules():
+            m.__dict__["_pk"] = self
+        return self
+
+    def detach(self):
+        for m in self.model.modules():
+            m.__dict__.pop("_pk", None)
+
+    # ---- called by the model's fine-tuning forward in place of AG.conv_w / AG.GroupNormWFn / AG.LayerNormWFn -----------------
+    def conv(self, x, weight, bias, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None,
+             residual=None):
+        e = self.gemms.get(id(weight))
+        if e is None:
+            e = self.gemms[id(weight)] = _Gemm(weight, bias, pw, live_out, live_in)
+        assert e.pw is pw, "the plan's packs were rebuilt under a packed trainer (call PackedTrainer after the last set_structure)"
+        return AG.conv_p(x, e.P, e.Pb, e.pw, e.get_bwd, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=residual)
+
+    def groupnorm(self, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live):
+        a = self.affines.get(id(gamma_p))
+        if a is None:
+            a = self.affines[id(gamma_p)] = _Affine(gamma_p, beta_p, gamma, beta, live)
+        return AG.GroupNormWFn.apply(x, a.Pg, a.Pb, a.Pg, a.Pb, groups, eps, silu, C, None)
+
+    def layernorm(self, x, gamma_p, beta_p, gamma, beta, eps):
+        a = self.affines.get(id(gamma_p))
+        if a is None:
+            a = self.affines[id(gamma_p)] = _Affine(gamma_p, beta_p, gamma, beta, None)
+        return AG.LayerNormWFn.apply(x, a.Pg, a.Pb, a.Pg, a.Pb, eps)
+
+    # ---- optimizer-facing API ---------------------------------------------------------------------------------------------------
+    def materialize(self, *forward_args, **forward_kwargs):
+        """one forward + backward (on a zero loss scale) so that every entry, including the data-gradient operands, exists.
+        Runs on a side stream: autograd anchors a parameter's AccumulateGrad node to the stream of its first backward and
+        re-uses the node while any graph that reached it is alive; a node anchored to the legacy default stream cannot take
+        part in a later HIP-graph capture (hipStreamEndCapture dies on the cross-stream edge)."""
+        if torch.cuda.is_available():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = self.model(*forward_args, **forward_kwargs).sample
+                (out.float().sum() * 0.0).backward()
+                del out
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            out = self.model(*forward_args, **forward_kwargs).sample
+            (out.float().sum() * 0.0).backward()
+            del out
+        for p in self.parameters():
+            p.grad = None
+        return self
+
+    def parameters(self) -> List[nn.Parameter]:
+        ps: List[nn.Parameter] = []
+        for e in self.gemms.values():
+            ps.append(e.P)
+            if e.Pb is not None:
+                ps.append(e.Pb)
+        for a in self.affines.values():
+            ps += [a.Pg, a.Pb]
+        return ps
+
+    def n_trainable(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    @torch.no_grad()
+    def offload_masters_(self):
+        """Move the diffusers-layout masters of the model to host memory (they are only the checkpoint interface while the
+        packed state trains; ``export_`` writes into them wherever they live): -3.5 GB of HBM for an SD-2.1 expert."""
+        for p in self.model.parameters():
+            if p.device.type != "cpu":
+                p.data = p.data.cpu()
+        return self
+
+    @torch.no_grad()
+    def refresh_(self):
+        """shadows <- masters: one multi-tensor cast for the forward operands, one strided copy per data-gradient operand"""
+        es = list(self.gemms.values())
+        torch._foreach_copy_([e.pw.w for e in es], [e.P.detach() for e in es])
+        for e in es:
+            e.refresh_bwd_()
+
+    @torch.no_grad()
+    def export_(self):
+        """write the packed values back into the diffusers-named full-shape parameters (checkpoint interface)"""
+        for e in self.gemms.values():
+            e.export_()
+        for a in self.affines.values():
+            a.export_()
+        return self.model

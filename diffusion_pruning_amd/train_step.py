@@ -557,7 +557,134 @@ class FineTunerStep:
         if self.reducer is not None:
             self.reducer.finish()
         optimizer.step()
-        # the bf16 packs follow the fp32 masters through the parameters' version counters (unet._PlanCache): the next
-        # forward re-packs what the optimizer changed; dropping the old packs now only returns their memory earlier
-        self.student.invalidate_plans()
+        pk = self.student.__dict__.get("_pk")
+        if pk is not None:
+            pk.refresh_()                     # packed masters (packed_train.py): one multi-tensor cast, no re-pack
+        else:
+            # the bf16 packs follow the fp32 masters through the parameters' version counters (unet._PlanCache): the next
+            # forward re-packs what the optimizer changed; dropping the old packs now only returns their memory earlier
+            self.student.invalidate_plans()
         return out
+
+
+class GraphedFineTunerStep(FineTunerStep):
+    """Expert fine-tuning with the trainable state in the kernels' layout (packed_train.PackedTrainer) and the whole step
+    replayed from ONE HIP graph: dense teacher forward, pruned student forward, the three loss terms (trainer.py:1730-1763),
+    backward incl. weight gradients, fused AdamW (trainer.py:1529-1540) and the refresh of the bf16 operands.  Nothing in the step touches the host, so the ~10^4 launches of the eager step (which is host-bound) cost
+    their device time only.  Same numbers as FineTunerStep on packed masters (tests/test_finetune_gpu.py)."""
+
+    def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None,
+                 lr: float = 1e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8):
+        super().__init__(student, teacher, cfg, schedule)
+        from .packed_train import PackedTrainer
+        self.trainer = PackedTrainer(student).attach()
+        self.opt_kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+        self.optimizer = None
+        self._cap = None
+
+    def _losses(self, model_pred, full_pred, w, target):
+        cfg = self.cfg
+        if cfg.snr_gamma is None:
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+        else:
+            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
+            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
+        diff = loss.detach()
+        total = loss * cfg.diffusion_weight
+        blk = torch.zeros((), device=model_pred.device)
+        if cfg.block_weight > 0:
+            for k in self.acts_s:
+                blk = blk + F.mse_loss(self.acts_s[k].float(), self.acts_t[k].detach().float(), reduction="mean")
+            blk = blk / len(self.acts_s)
+            total = total + cfg.block_weight * blk
+        dist_l = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")
+        total = total + cfg.distillation_weight * dist_l
+        return total, diff, dist_l.detach(), blk.detach()
+
+    def _snr_weights(self, timesteps):
+        cfg = self.cfg
+        if cfg.snr_gamma is None:
+            return torch.ones(timesteps.shape[0], device=timesteps.device)
+        snr = compute_snr(self.schedule, timesteps)
+        if cfg.prediction_type == "v_prediction":
+            snr = snr + 1
+        return (torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr).float()
+
+    def capture(self, batch: dict, warmup_iters: int = 2, offload_masters: bool = False, _diag: str = ""):
+        """Build the packed trainable state, the fused AdamW and ONE HIP graph of the whole step (teacher forward, student
+        forward, losses, backward, optimizer, operand refresh) for this batch geometry.  The warm-up iterations that
+        PyTorch's whole-network capture needs are real optimizer steps; parameters and optimizer state are put back to
+        their values before them once the graph exists."""
+        dev = batch["noisy_latents"].device
+        st = {k: batch[k].clone() for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target")}
+        if self.schedule.alphas_cumprod.device != dev:
+            self.schedule.alphas_cumprod = self.schedule.alphas_cumprod.to(dev)
+        st["snr_w"] = self._snr_weights(st["timesteps"])
+        self.trainer.materialize(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"])
+        # the block-output hooks kept the materialising forward's autograd graph (and through it every AccumulateGrad node)
+        # alive: drop it before the warm-up builds the graphs the capture will re-use
+        self.acts_s.clear()
+        self.acts_t.clear()
+        if offload_masters:
+            self.trainer.offload_masters_()
+            torch.cuda.empty_cache()
+        params = self.trainer.parameters()
+        self.optimizer = torch.optim.AdamW(params, fused=True, capturable=True, **self.opt_kw)
+        out = {}
+
+        def one_step():
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.no_grad():
+                full_pred = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
+            pred = self.student(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
+            if "simpleloss" in _diag:
+                total = pred.float().pow(2).mean()
+                diff = dist_l = blk = total.detach()
+            else:
+                total, diff, dist_l, blk = self._losses(pred, full_pred, st["snr_w"], st["target"])
+            total.backward()
+            self.optimizer.step()
+            self.trainer.refresh_()
+            out.update(total=total.detach(), diff=diff, dist=dist_l, blk=blk)
+
+        import os as _os
+        import sys as _sys
+        _tr = (lambda m: print("[ft-capture]", m, file=_sys.stderr, flush=True)) if _os.environ.get("APTP_FT_TRACE") else (lambda m: None)
+        saved = [p.detach().clone() for p in params]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup_iters):
+                one_step()
+                _tr(f"warm-up {i} issued")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        _tr("warm-up done")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_step()
+            _tr("captured body")
+        _tr("capture ended")
+        with torch.no_grad():                       # undo the warm-up steps (the capture itself executes nothing)
+            for p, v in zip(params, saved):
+                p.copy_(v)
+            for stt in self.optimizer.state.values():
+                for t in stt.values():
+                    if torch.is_tensor(t):
+                        t.zero_()
+            self.trainer.refresh_()
+        del saved
+        self._cap = dict(st=st, graph=graph, **out)
+        return self
+
+    def train_step(self, optimizer=None, batch: Optional[dict] = None):
+        """one replayed step on `batch` (same shapes as the captured one); `optimizer` is ignored: the fused AdamW built at
+        capture time is part of the graph"""
+        cap = self._cap
+        assert cap is not None, "call capture(batch) first"
+        with torch.no_grad():
+            for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target"):
+                cap["st"][k].copy_(batch[k])
+            cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
+        cap["graph"].replay()
+        return {"loss": cap["total"], "diff_loss": cap["diff"], "distillation_loss": cap["dist"], "block_loss": cap["blk"]}

@@ -130,6 +130,32 @@ def _take_dst(mod, B: int, H: int, W: int, C: int, device) -> Optional[torch.Ten
     return d[0].view(d[1], B, H, W, C, device)
 
 
+def _cw(mod, x, weight, bias, pw, get_bwd, **kw):
+    """weight-gradient convolution of the fine-tuning path: diffusers-layout masters (AG.conv_w) or, under a PackedTrainer
+    (packed_train.py), the packed masters"""
+    from . import autograd as AG
+    pk = mod.__dict__.get("_pk")
+    if pk is not None:
+        return pk.conv(x, weight, bias, pw, get_bwd, **kw)
+    return AG.conv_w(x, weight, bias, pw, get_bwd, **kw)
+
+
+def _gnw(mod, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live):
+    from . import autograd as AG
+    pk = mod.__dict__.get("_pk")
+    if pk is not None:
+        return pk.groupnorm(x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live)
+    return AG.GroupNormWFn.apply(x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live)
+
+
+def _lnw(mod, x, gamma_p, beta_p, gamma, beta, eps):
+    from . import autograd as AG
+    pk = mod.__dict__.get("_pk")
+    if pk is not None:
+        return pk.layernorm(x, gamma_p, beta_p, gamma, beta, eps)
+    return AG.LayerNormWFn.apply(x, gamma_p, beta_p, gamma, beta, eps)
+
+
 def _capturing() -> bool:
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
@@ -137,6 +163,8 @@ def _capturing() -> bool:
 def _versions(mod: nn.Module) -> tuple:
     """in-place update counters of a module's parameters: optimizer steps, ``param.data.copy_`` and ``load_state_dict``
     all bump them, so packs made from older values can be recognised as stale without any hook on the training loop"""
+    if mod.__dict__.get("_pk") is not None:
+        return ()      # under a PackedTrainer the diffusers-layout masters are not what is trained: the packs ARE the state
     ps = mod.__dict__.get("_vparams")
     if ps is None:
         ps = mod.__dict__["_vparams"] = list(mod.parameters())      # (dropped by invalidate(): .to() may replace parameters)
@@ -359,22 +387,22 @@ class ResnetBlock2DWidthGated(nn.Module):
         if self.depth_gated and (self.dropped or self._depth_state()[0] == 0.0):
             return _nchw(x_in)
         live = pl["live"]
-        a1 = AG.GroupNormWFn.apply(x, self.norm1.weight, self.norm1.bias, pl["g1"], pl["b1"], self.groups, self.eps, True, Cin, None)
+        a1 = _gnw(self, x, self.norm1.weight, self.norm1.bias, pl["g1"], pl["b1"], self.groups, self.eps, True, Cin, None)
         if "temb_pw" not in pl:
             pl["temb_pw"] = ops.pack_weight(pl["temb_w"], pl["temb_b"], device=dev)
         emb_silu = temb.emb_silu if isinstance(temb, TembBundle) else torch.nn.functional.silu(temb.float()).to(torch.bfloat16)
-        tproj = AG.conv_w(emb_silu[None], self.time_emb_proj.weight, self.time_emb_proj.bias, pl["temb_pw"],
+        tproj = _cw(self, emb_silu[None], self.time_emb_proj.weight, self.time_emb_proj.bias, pl["temb_pw"],
                           self._sel_bwd_pack(pl, "temb", self.time_emb_proj.weight, dev, live), pad=0, out_f32=True, live_out=live)[0]
-        h = AG.conv_w(a1, self.conv1.weight, self.conv1.bias, pl["w1"], self._sel_bwd_pack(pl, "w1", self.conv1.weight, dev, live),
+        h = _cw(self, a1, self.conv1.weight, self.conv1.bias, pl["w1"], self._sel_bwd_pack(pl, "w1", self.conv1.weight, dev, live),
                       live_out=live)
         h = (h.float() + tproj[:, None, None, :]).to(torch.bfloat16)
-        a2 = AG.GroupNormWFn.apply(h, self.norm2.weight, self.norm2.bias, pl["g2"], pl["b2"], pl["k_live"], self.eps, True,
+        a2 = _gnw(self, h, self.norm2.weight, self.norm2.bias, pl["g2"], pl["b2"], pl["k_live"], self.eps, True,
                                    pl["c_live"], live)
         sc = x
         if self.conv_shortcut is not None:
-            sc = AG.conv_w(x, self.conv_shortcut.weight, self.conv_shortcut.bias, pl["wsc"],
+            sc = _cw(self, x, self.conv_shortcut.weight, self.conv_shortcut.bias, pl["wsc"],
                            self._sel_bwd_pack(pl, "wsc", self.conv_shortcut.weight, dev), pad=0)
-        out = AG.conv_w(a2, self.conv2.weight, self.conv2.bias, pl["w2"],
+        out = _cw(self, a2, self.conv2.weight, self.conv2.bias, pl["w2"],
                         self._sel_bwd_pack(pl, "w2", self.conv2.weight, dev, None, live), live_in=live) + sc
         return _nchw(out)
 
@@ -755,21 +783,28 @@ class Transformer2DModelWidthGated(nn.Module):
 
         def lin(xx, name, mod, lo=None, li=None):
             b = mod.bias
-            return AG.conv_w(xx, mod.weight, b, pack(name, mod.weight, b, lo, li), bwd(name, mod.weight, lo, li), pad=0,
+            return _cw(self, xx, mod.weight, b, pack(name, mod.weight, b, lo, li), bwd(name, mod.weight, lo, li), pad=0,
                              live_out=lo, live_in=li)
 
         def live_of(gate, width):
-            m = gate.hard_uniform()
-            if m is None or bool((m == 1).all()):
-                return None, None
-            return _live_index(m, width).to(dev), int(m.sum())
+            # (cached in the plan: the index tensor is uploaded once, never while a stream is capturing)
+            key = ("live", id(gate))
+            ent = pl.get(key)
+            if ent is None:
+                m = gate.hard_uniform()
+                if m is None or bool((m == 1).all()):
+                    ent = (None, None)
+                else:
+                    ent = (_live_index(m, width).to(dev), int(m.sum()))
+                pl[key] = ent
+            return ent
 
-        a = AG.GroupNormWFn.apply(x, self.norm.weight, self.norm.bias, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False, C, None)
+        a = _gnw(self, x, self.norm.weight, self.norm.bias, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False, C, None)
         tok = a.reshape(B, P, C)
         x_tok = x.reshape(B, P, C)
         h = lin(tok, "proj_in", self.proj_in)
         # self attention
-        n = AG.LayerNormWFn.apply(h, tb.norm1.weight, tb.norm1.bias, pl["ln1_g"], pl["ln1_b"], 1e-5)
+        n = _lnw(self, h, tb.norm1.weight, tb.norm1.bias, pl["ln1_g"], pl["ln1_b"], 1e-5)
         a1 = tb.attn1
         l1, h1 = live_of(a1.gate, 64)
         h1 = a1.heads if h1 is None else h1
@@ -777,7 +812,7 @@ class Transformer2DModelWidthGated(nn.Module):
         o = AG.SelfAttnFn.apply(qkv, h1)
         h = lin(o, "a1o", a1.to_out[0], None, l1) + h
         # cross attention
-        n = AG.LayerNormWFn.apply(h, tb.norm2.weight, tb.norm2.bias, pl["ln2_g"], pl["ln2_b"], 1e-5)
+        n = _lnw(self, h, tb.norm2.weight, tb.norm2.bias, pl["ln2_g"], pl["ln2_b"], 1e-5)
         a2 = tb.attn2
         l2, h2 = live_of(a2.gate, 64)
         h2 = a2.heads if h2 is None else h2
@@ -788,7 +823,7 @@ class Transformer2DModelWidthGated(nn.Module):
         o = AG.CrossAttnFn.apply(q, kv, h2)
         h = lin(o, "a2o", a2.to_out[0], None, l2) + h
         # feed-forward
-        n = AG.LayerNormWFn.apply(h, tb.norm3.weight, tb.norm3.bias, pl["ln3_g"], pl["ln3_b"], 1e-5)
+        n = _lnw(self, h, tb.norm3.weight, tb.norm3.bias, pl["ln3_g"], pl["ln3_b"], 1e-5)
         geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
         lf, _ = live_of(geglu.gate, geglu.dim_out // geglu.gate.width)
         lo2 = None if lf is None else torch.cat([lf, lf + geglu.dim_out])
@@ -946,7 +981,7 @@ class Downsample2D(nn.Module):
         self._pinned = self._pinned or _capturing()
         if torch.is_grad_enabled() and self.conv.weight.requires_grad:
             from . import autograd as AG
-            return _nchw(AG.conv_w(x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), stride=2, pad=1))
+            return _nchw(_cw(self, x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), stride=2, pad=1))
         if torch.is_grad_enabled() and x.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), stride=2, pad=1))
@@ -988,7 +1023,7 @@ class Upsample2D(nn.Module):
         self._pinned = self._pinned or _capturing()
         if torch.is_grad_enabled() and self.conv.weight.requires_grad:
             from . import autograd as AG
-            return _nchw(AG.conv_w(x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), ups=1))
+            return _nchw(_cw(self, x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), ups=1))
         if torch.is_grad_enabled() and x.requires_grad:
             from . import autograd as AG
             return _nchw(AG.conv(x, self._pw, self._get_bwd(x.device), ups=1))
@@ -1429,8 +1464,8 @@ class UNet2DConditionModelGated(nn.Module):
         return [m for m in self.modules() if isinstance(m, Transformer2DModelWidthGated)]
 
     def _misc_packs(self, dev):
-        ver = tuple(p._version for mod in (self.conv_in, self.time_embedding, self.conv_norm_out, self.conv_out)
-                    for p in mod.parameters())
+        ver = () if self.__dict__.get("_pk") is not None else \
+            tuple(p._version for mod in (self.conv_in, self.time_embedding, self.conv_norm_out, self.conv_out) for p in mod.parameters())
         if self._misc is not None and self._misc["dev"] == str(dev) and self._misc["ver"] == ver:
             self._misc["pinned"] = self._misc["pinned"] or _capturing()
         if self._misc is None or self._misc["dev"] != str(dev) or self._misc["ver"] != ver:
@@ -1573,15 +1608,15 @@ class UNet2DConditionModelGated(nn.Module):
         ang = timesteps.float()[:, None] * misc["freqs"][None, :]
         t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
         te = self.time_embedding
-        e1 = AG.conv_w(t_emb[None], te.linear_1.weight, te.linear_1.bias, misc["t1"], bwd("t1_bwd", te.linear_1.weight), pad=0, out_f32=True)
+        e1 = _cw(self, t_emb[None], te.linear_1.weight, te.linear_1.bias, misc["t1"], bwd("t1_bwd", te.linear_1.weight), pad=0, out_f32=True)
         e1 = torch.nn.functional.silu(e1).to(torch.bfloat16)
-        e2 = AG.conv_w(e1, te.linear_2.weight, te.linear_2.bias, misc["t2"], bwd("t2_bwd", te.linear_2.weight), pad=0, out_f32=True)
+        e2 = _cw(self, e1, te.linear_2.weight, te.linear_2.bias, misc["t2"], bwd("t2_bwd", te.linear_2.weight), pad=0, out_f32=True)
         temb = TembBundle(emb_silu=torch.nn.functional.silu(e2)[0].to(torch.bfloat16))
         ctx = CtxBundle(ehs=encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous())
         x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
         x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
         live_in = torch.arange(self.in_channels, device=dev)
-        h = _nchw(AG.conv_w(x, self.conv_in.weight, self.conv_in.bias, misc["conv_in"], bwd("conv_in_bwd", self.conv_in.weight),
+        h = _nchw(_cw(self, x, self.conv_in.weight, self.conv_in.bias, misc["conv_in"], bwd("conv_in_bwd", self.conv_in.weight),
                             live_in=live_in))
         res_samples = (h,)
         for blk in self.down_blocks:
@@ -1593,10 +1628,10 @@ class UNet2DConditionModelGated(nn.Module):
             res = res_samples[-n_res:]
             res_samples = res_samples[:-n_res]
             h = blk(hidden_states=h, temb=temb, res_hidden_states_tuple=res, encoder_hidden_states=ctx)
-        a = AG.GroupNormWFn.apply(_nhwc(h), self.conv_norm_out.weight, self.conv_norm_out.bias, misc["gn_g"], misc["gn_b"],
+        a = _gnw(self, _nhwc(h), self.conv_norm_out.weight, self.conv_norm_out.bias, misc["gn_g"], misc["gn_b"],
                                   self.conv_norm_out.num_groups, self.conv_norm_out.eps, True, self.conv_norm_out.num_channels, None)
         live_out = torch.arange(self.out_channels, device=dev)
-        y = AG.conv_w(a, self.conv_out.weight, self.conv_out.bias, misc["conv_out"], bwd("conv_out_bwd", self.conv_out.weight),
+        y = _cw(self, a, self.conv_out.weight, self.conv_out.bias, misc["conv_out"], bwd("conv_out_bwd", self.conv_out.weight),
                       out_f32=True, live_out=live_out)
         out = y[..., :self.out_channels].permute(0, 3, 1, 2).to(sample.dtype)
         if not return_dict:

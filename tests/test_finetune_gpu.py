@@ -90,3 +90,82 @@ def test_finetune_step_updates_only_live_parameters(cuda):
     keep = mask["width"][0][0].bool().repeat_interleave(w.shape[0] // 32)
     assert float(delta[keep].min()) > 0 and float(delta[~keep].max()) == 0.0
     assert l1 < l0 * 1.5
+
+
+def _two_students(cuda, mask):
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    cfg, a, params = build(cuda, mask)
+    _, b, _ = build(cuda, mask)
+    teacher = UNet2DConditionModelGated(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
+                                        cross_attention_dim=cfg.cross_attention_dim)
+    teacher.load_state_dict({k: v.detach() for k, v in params.items()})
+    teacher.to(cuda).freeze()
+    teacher.set_structure({k: [v.to(cuda) for v in vs] for k, vs in O.ones_mask(cfg).items()})
+    return cfg, a, b, teacher
+
+
+def test_packed_masters_train_like_diffusers_layout_masters(cuda):
+    """packed_train.PackedTrainer: the optimizer owns compact fp32 tensors in the kernels' order; one SGD step on them, written
+    back with export_(), equals one SGD step on the diffusers-layout masters (same kernels produce the gradients; only the
+    scatter into full-shape tensors and the re-pack disappear)"""
+    from diffusion_pruning_amd.packed_train import PackedTrainer
+    from diffusion_pruning_amd.train_step import FineTunerStep, synthetic_batch
+    mask = O.random_mask(O.TINY, 0.5, 8, n_depth_off=1)
+    cfg, sa, sb, teacher = _two_students(cuda, mask)
+    batch = synthetic_batch(2, 16, cuda, seed=4, cross_dim=cfg.cross_attention_dim)
+    step_a = FineTunerStep(sa, teacher)
+    opt_a = torch.optim.SGD([p for p in sa.parameters() if p.requires_grad], lr=1e-2)
+    la = float(step_a.train_step(opt_a, batch)["loss"].detach())
+    step_a.remove_hooks() if hasattr(step_a, "remove_hooks") else None
+    step_b = FineTunerStep(sb, teacher)
+    pk = PackedTrainer(sb).attach().materialize(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"])
+    n_pk, n_full = pk.n_trainable(), sum(p.numel() for p in sb.parameters())
+    assert n_pk < 0.8 * n_full                        # dead channels / heads / chunks / the dropped block carry no state
+    opt_b = torch.optim.SGD(pk.parameters(), lr=1e-2)
+    lb = float(step_b.train_step(opt_b, batch)["loss"].detach())
+    assert abs(la - lb) <= 1e-5 * abs(la)
+    pk.export_()
+    worst = 0.0
+    for (na, pa), (nb, pb) in zip(sa.named_parameters(), sb.named_parameters()):
+        assert na == nb
+        d = float((pa.detach() - pb.detach()).abs().max())
+        worst = max(worst, d / (float(pa.detach().abs().max()) + 1e-12))
+    check(worst, 1e-5, "max relative parameter difference after one SGD step (packed vs diffusers-layout masters)")
+    # the second forward runs on the refreshed shadows: same loss as the reference path's second step
+    la2 = float(step_a.train_step(opt_a, batch)["loss"].detach())
+    lb2 = float(step_b.train_step(opt_b, batch)["loss"].detach())
+    assert abs(la2 - lb2) <= 2e-3 * abs(la2) and la2 != la
+
+
+def test_graphed_finetune_step_equals_the_eager_packed_step(cuda):
+    """GraphedFineTunerStep (teacher forward; student forward + losses + backward + fused AdamW + operand refresh as HIP
+    graphs) reproduces the eager packed step: losses of three consecutive steps and the parameters after them"""
+    from diffusion_pruning_amd.packed_train import PackedTrainer
+    from diffusion_pruning_amd.train_step import FineTunerStep, GraphedFineTunerStep, synthetic_batch
+    mask = O.random_mask(O.TINY, 0.6, 9, n_depth_off=1)
+    cfg, sa, sb, teacher = _two_students(cuda, mask)
+    batches = [synthetic_batch(2, 16, cuda, seed=s, cross_dim=cfg.cross_attention_dim) for s in (4, 5, 6)]
+    kw = dict(lr=1e-4, weight_decay=1e-2)
+    eager = FineTunerStep(sa, teacher)
+    pk = PackedTrainer(sa).attach().materialize(batches[0]["noisy_latents"], batches[0]["timesteps"], batches[0]["encoder_hidden_states"])
+    opt = torch.optim.AdamW(pk.parameters(), fused=True, **kw)
+    ref = [float(eager.train_step(opt, b)["loss"].detach()) for b in batches]
+    graphed = GraphedFineTunerStep(sb, teacher, **kw)
+    graphed.capture(batches[0], offload_masters=True)     # the diffusers-layout masters wait on the host meanwhile
+    got = []
+    for b in batches:
+        got.append(float(graphed.train_step(None, b)["loss"]))
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert abs(a - b) <= 2e-3 * abs(a), (ref, got)
+    pa = torch.cat([p.detach().flatten() for p in pk.parameters()])
+    pb = torch.cat([p.detach().flatten() for p in graphed.trainer.parameters()])
+    assert pa.shape == pb.shape
+    check(rel_l2(pb.cpu(), pa.cpu()), 1e-4, "parameters after three AdamW steps (graphed vs eager)")
+    # checkpoint interface: export_() writes the trained values back into the diffusers-named masters (on the host here)
+    before = sb.down_blocks[0].resnets[0].conv1.weight.detach().clone()
+    graphed.trainer.export_()
+    after = sb.down_blocks[0].resnets[0].conv1.weight.detach()
+    assert after.device.type == "cpu" and float((after - before).abs().max()) > 0
+    pk.export_()
+    assert torch.equal(sa.down_blocks[0].resnets[0].conv1.weight.detach().cpu(), after)

@@ -198,9 +198,60 @@ def _load_tuning():
     return {}
 
 
-# (tile, split_k) per GEMM shape measured on MI355X by tools/tune_convs.py; shapes not in the table fall back to the
-# library heuristic (aptp_conv_gemm_suggest_split_k / pick_tile).
+# (tile, split_k) per GEMM shape measured on MI355X by tools/tune_convs.py.  The table holds the shapes of the headline
+# mask, the dense model and the pruning step; every OTHER architecture code (config 5's experts, real APTP experts with
+# irregular widths) produces shapes that are not in it.  Those take the entry of the NEAREST tuned shape of the same class
+# (taps, stride, upsampling, GEGLU, second operand) in log-space distance over (M, N, K) -- the tile engine's behaviour
+# changes smoothly with the extents, while the library heuristic only knows the generic non-DMA tiles (measured on a
+# 55 %-keep expert: 29 us per launch on conv_gemm_kernel<64,128> where the neighbours' DMA tiles take ~20).  Beyond
+# TUNING_MAX_DIST the heuristic (aptp_conv_gemm_suggest_split_k / pick_tile) decides.  APTP_TUNING_NEAREST=0 disables.
 TUNING = _load_tuning()
+TUNING_NEAREST = os.environ.get("APTP_TUNING_NEAREST", "1") != "0"
+TUNING_MAX_DIST = 2.0
+_HALO_TILES = (43, 44)
+_tuning_index = None
+_tuning_near_cache = {}
+
+
+def _tuning_classes():
+    global _tuning_index
+    if _tuning_index is None:
+        import re
+        idx = {}
+        pat = re.compile(r"M(\d+)_N(\d+)_C(\d+)_T(\d+)_s(\d+)u(\d+)g(\d+)(?:x(\d+))?$")
+        for k, v in TUNING.items():
+            m = pat.match(k)
+            if not m:
+                continue
+            M, N, C, T, s_, u, g, x2 = (int(t) if t else 0 for t in m.groups())
+            idx.setdefault((T, s_, u, g, x2 > 0), []).append((M, N, T * C + x2, v))
+        _tuning_index = idx
+    return _tuning_index
+
+
+def tuning_lookup(M, N, Cin, taps, stride, ups, geglu, Cin2: int = 0):
+    """exact table entry, else the nearest tuned shape of the same class (None when there is none close enough)"""
+    key = tuning_key(M, N, Cin, taps, stride, ups, geglu, Cin2)
+    hit = TUNING.get(key)
+    if hit is not None or not TUNING_NEAREST:
+        return hit
+    if key in _tuning_near_cache:
+        return _tuning_near_cache[key]
+    import math
+    K = taps * Cin + Cin2
+    best, bd = None, TUNING_MAX_DIST
+    for (M2, N2, K2, v) in _tuning_classes().get((taps, stride, ups, int(bool(geglu)), Cin2 > 0), ()):
+        if v["tile"] in _HALO_TILES and M2 != M:
+            continue                      # the halo-in-LDS tiles are tied to the map width
+        d = 1.5 * abs(math.log2(M / M2)) + abs(math.log2(N / N2)) + abs(math.log2(K / K2))
+        if d < bd:
+            best, bd = v, d
+    if best is not None:
+        nK = (K + BK - 1) // BK
+        best = dict(best)
+        best["split_k"] = max(1, min(int(best["split_k"]), nK // 4 if nK >= 8 else 1))
+    _tuning_near_cache[key] = best
+    return best
 
 # Optional launch recorder used by bench.py's roofline leg: when a list, every aptp_conv_gemm launch appends
 # {"params": ConvGemmParams, "flops": algorithmic FLOPs, "keep": tensors referenced by the params}.
@@ -460,7 +511,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     in_kernel = None                 # split-K form: tuned per shape; untuned shapes combine in-kernel up to 4 slices
     explicit_split = split_k is not None
     if split_k is None and tile == 0:
-        tuned = TUNING.get(tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2))
+        tuned = tuning_lookup(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2)
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
             in_kernel = bool(tuned.get("in_kernel", 0))

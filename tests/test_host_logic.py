@@ -271,3 +271,19 @@ def test_prefetch_plan_is_per_thread_and_scoped_to_the_forward(tiny):
     th = threading.Thread(target=lambda: other.setdefault("plan", ops._current_prefetch_plan()))
     th.start(); th.join()
     assert other["plan"] is None                    # another thread never sees this thread's plan
+
+
+def test_tuning_lookup_falls_back_to_the_nearest_tuned_shape_of_the_same_class():
+    """shapes of architecture codes that were never tuned (config 5's experts) take the tile of the closest tuned shape"""
+    from diffusion_pruning_amd import ops
+    exact = ops.tuning_lookup(16384, 320, 320, 1, 1, 0, False)
+    assert exact is ops.TUNING[ops.tuning_key(16384, 320, 320, 1, 1, 0, False)]
+    near = ops.tuning_lookup(16384, 328, 320, 1, 1, 0, False)               # a 41-group expert width: not in the table
+    assert near is not None and near["tile"] == exact["tile"]
+    assert ops.tuning_lookup(16384, 328, 320, 1, 1, 0, False) is near       # cached
+    assert ops.tuning_lookup(24, 40, 72, 1, 1, 0, False) is None            # nothing within reach: the library heuristic decides
+    far3x3 = ops.tuning_lookup(16384, 176, 352, 9, 1, 0, False)
+    assert far3x3 is not None and far3x3["tile"] not in ops._HALO_TILES
+    # a neighbour's split-K never leaves a slice with fewer than four K-steps
+    deep = ops.tuning_lookup(256, 1280, 1200, 9, 1, 0, False)
+    assert deep is not None and deep["split_k"] <= max(1, (9 * 1200 // 64) // 4)

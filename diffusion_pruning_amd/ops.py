@@ -512,6 +512,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     explicit_split = split_k is not None
     if split_k is None and tile == 0:
         tuned = tuning_lookup(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2)
+        if tuned is not None and tuned["tile"] >= 7 and max(pw.cin_pad, pw.cin2_pad) > 4032:
+            tuned = None                   # the LDS-DMA tiles address at most 4032 channels per tap (a neighbour's tile may be one)
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
             in_kernel = bool(tuned.get("in_kernel", 0))

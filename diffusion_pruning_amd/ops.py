@@ -22,6 +22,11 @@ from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionP
                    ColsumParams, LayerNormPgradParams)
 
 BK = 64
+# Storage type of activations and packed weights.  The HIP kernels exist for bf16 only (MFMA operands); the test-only CPU
+# emulator (tests/hip_emulator.py) can switch both to fp32 to run the SAME host logic -- compaction, GroupNorm-beta
+# correction, gate plumbing, batched time / text projections, in-place skip-concats, depth lerp -- without any rounding and
+# compare it with the fp32 oracle at 1e-5 (tests/test_host_logic.py); the kernels themselves refuse anything but bf16.
+ACT_DTYPE = torch.bfloat16
 
 
 def _stream() -> int:
@@ -150,8 +155,8 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out_idx
     N, Cin, KH, KW = w.shape
     cin_live = round_up(Cin, cin_pad_to)
     cin_pad = round_up(cin_live, BK)
-    packed = torch.zeros(N, KH * KW, cin_pad, dtype=torch.bfloat16, device=device)
-    packed[:, :, :Cin] = w.permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(torch.bfloat16)
+    packed = torch.zeros(N, KH * KW, cin_pad, dtype=ACT_DTYPE, device=device)
+    packed[:, :, :Cin] = w.permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(ACT_DTYPE)
     colsum = packed.float().sum(dim=(1, 2)).contiguous() if ln_gamma is not None else None
     return PackedWeight(packed.contiguous(), None if bias is None else bias.contiguous(), N, cin_live, KH, KW, geglu, colsum)
 
@@ -170,8 +175,8 @@ def pack_weight_cat(pw: PackedWeight, w2: torch.Tensor, bias2: Optional[torch.Te
     assert n_live <= pw.N
     c2_live = round_up(c2, 8)
     c2_pad = round_up(c2_live, BK)
-    ext = torch.zeros(pw.N, c2_pad, dtype=torch.bfloat16, device=dev)
-    ext[:n_live, :c2] = w2.to(torch.bfloat16)
+    ext = torch.zeros(pw.N, c2_pad, dtype=ACT_DTYPE, device=dev)
+    ext[:n_live, :c2] = w2.to(ACT_DTYPE)
     flat = torch.cat([pw.w.reshape(pw.N, -1), ext], 1).reshape(pw.N, 1, -1).contiguous()
     bias = pw.bias
     if bias2 is not None:

@@ -116,7 +116,7 @@ class _CatSlot:
         if C != (self.ch if which == 0 else self.cs):
             return None
         if self.buf is None:
-            self.buf = torch.empty(B, H, W, self.ch + self.cs, dtype=torch.bfloat16, device=device)
+            self.buf = torch.empty(B, H, W, self.ch + self.cs, dtype=ops.ACT_DTYPE, device=device)
         elif tuple(self.buf.shape[:3]) != (B, H, W) or self.buf.device != device:
             return None
         return self.buf[..., :self.ch] if which == 0 else self.buf[..., self.ch:]
@@ -457,7 +457,7 @@ class ResnetBlock2DWidthGated(nn.Module):
             emb_silu = temb.emb_silu
         else:
             # standalone use with a raw [B, T] embedding: SiLU then this block's own projection
-            emb_silu = torch.nn.functional.silu(temb.float()).to(torch.bfloat16)
+            emb_silu = torch.nn.functional.silu(temb.float()).to(ops.ACT_DTYPE)
         pw = pl.get("temb_pw")
         if pw is None:
             pw = ops.pack_weight(pl["temb_w"], pl["temb_b"], device=emb_silu.device)
@@ -919,7 +919,7 @@ class Transformer2DModelWidthGated(nn.Module):
                 return kv
             ehs_t = ehs.ehs
         else:
-            ehs_t = ehs.to(device=dev, dtype=torch.bfloat16)
+            ehs_t = ehs.to(device=dev, dtype=ops.ACT_DTYPE)
         pw = pl.get("a2_kv")
         if pw is None:
             pw = ops.pack_weight(pl["a2_kv_w"], None, device=dev)
@@ -1524,7 +1524,7 @@ class UNet2DConditionModelGated(nn.Module):
         return self._batched.put(key, (), bp)
 
     def _project_context(self, encoder_hidden_states, bp, dev) -> CtxBundle:
-        ehs = encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous()
+        ehs = encoder_hidden_states.to(device=dev, dtype=ops.ACT_DTYPE).contiguous()
         # projections made with value-dependent (soft / per-sample) gates in the epilogue must not be reused
         reusable = not any(dense for (_, dense, _) in bp["kv_gates"])
         ctx = CtxBundle(ehs=ehs, key=bp["key"] if reusable else None)
@@ -1684,7 +1684,7 @@ class UNet2DConditionModelGated(nn.Module):
             x, t_emb = ops.unet_prologue(sample, timesteps, misc["freqs"], misc["cin_pad"])
         else:
             ang = timesteps.float()[:, None] * misc["freqs"][None, :]
-            t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
+            t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(ops.ACT_DTYPE)
             x = None
         e1 = ops.linear(t_emb[None], misc["t1"], act=ops.ACT_SILU)
         emb_silu = ops.linear(e1, misc["t2"], act=ops.ACT_SILU)           # bf16 [1, B, T] = SiLU(emb)
@@ -1704,7 +1704,7 @@ class UNet2DConditionModelGated(nn.Module):
 
         # 2. pre-process: conv_in on the channel-padded NHWC input
         if x is None:
-            x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=torch.bfloat16, device=dev)
+            x = torch.zeros(B, sample.shape[2], sample.shape[3], misc["cin_pad"], dtype=ops.ACT_DTYPE, device=dev)
             x[..., :self.in_channels] = sample.permute(0, 2, 3, 1)
         conv_in_dst = self._register_cat_slots(B, x.shape[1], x.shape[2], misc["conv_in"].N, dev)
         h = _nchw(ops.conv_gemm(x, misc["conv_in"], out=conv_in_dst, colstats=True))

@@ -1390,6 +1390,7 @@ class UNet2DConditionModelGated(nn.Module):
         width_vectors, depth_vectors = arch_vectors["width"], arch_vectors["depth"]
         # kept (by reference) so a checkpoint can record the installed architecture vector (checkpoint.arch_vector_of)
         self._installed_structure = {"width": list(width_vectors), "depth": list(depth_vectors)}
+        self._structure_epoch = self.__dict__.get("_structure_epoch", 0) + 1      # (identity of the installed code for graph caches)
         # one bulk device->host copy of all gates so per-module mode selection needs no further syncs
         self._host_map = {}
         if prefetch_hosts:

@@ -113,3 +113,91 @@ def test_scheduler_reconstructs_x0_for_exact_v():
     v = c[0] * eps - c[1] * x0
     prev = sch.step_coef(v, c, xt)
     assert torch.allclose(prev, c[2] * x0 + c[3] * eps, atol=1e-5)
+
+
+# ---- PNDM / PLMS (configs/img_generation/sd-2-1_cc3m.yaml:50; pruning_pipelines.py:810-814) --------------------------------
+def _plms_reference(model, x, N, prediction_type):
+    """PLMS with explicit history lists, written the way the published algorithm / diffusers' step_plms is structured
+    (counter, ets, cur_sample), in float64: the table-driven tensor form of PNDMSchedulerLite must agree with it."""
+    import numpy as np
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    ac = np.cumprod(1.0 - betas)
+    final = ac[0]
+    ratio = 1000 // N
+    base = (np.arange(0, N) * ratio).round().astype(np.int64) + 1
+    ts = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1]
+
+    def transfer(sample, t, t_prev, out):
+        a_t = ac[t]
+        a_p = ac[t_prev] if t_prev >= 0 else final
+        if prediction_type == "v_prediction":
+            out = a_t ** 0.5 * out + (1 - a_t) ** 0.5 * sample
+        return (a_p / a_t) ** 0.5 * sample - (a_p - a_t) * out / (a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5)
+
+    ets, counter, cur_sample = [], 0, None
+    x = x.double()
+    for t in ts.tolist():
+        out = model(x, t).double()
+        prev_t = t - ratio
+        if counter != 1:
+            ets = ets[-3:]
+            ets.append(out)
+        else:
+            prev_t, t = t, t + ratio
+        if len(ets) == 1 and counter == 0:
+            cur_sample = x
+        elif len(ets) == 1 and counter == 1:
+            out = (out + ets[-1]) / 2
+            x, cur_sample = cur_sample, None
+        elif len(ets) == 2:
+            out = (3 * ets[-1] - ets[-2]) / 2
+        elif len(ets) == 3:
+            out = (23 * ets[-1] - 16 * ets[-2] + 5 * ets[-3]) / 12
+        else:
+            out = (55 * ets[-1] - 59 * ets[-2] + 37 * ets[-3] - 9 * ets[-4]) / 24
+        x = transfer(x, t, prev_t, out)
+        counter += 1
+    return x
+
+
+@pytest.mark.parametrize("prediction_type", ["epsilon", "v_prediction"])
+@pytest.mark.parametrize("N", [4, 20, 50])
+def test_pndm_tables_equal_the_list_form_of_plms(prediction_type, N):
+    from diffusion_pruning_amd.pipeline import PNDMSchedulerLite
+    g = torch.Generator().manual_seed(N)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    Wm = torch.randn(4, 4, generator=g) * 0.3
+
+    def model(x, t):                                       # any deterministic function of (x, t)
+        return torch.tanh(torch.einsum("oc,bchw->bohw", Wm.to(x.dtype), x)) * 0.5 + 0.1 * (t / 1000.0)
+
+    ref = _plms_reference(model, x0, N, prediction_type)
+    sch = PNDMSchedulerLite(prediction_type=prediction_type)
+    ts = sch.set_timesteps(N)
+    assert len(ts) == N + 1 and int(ts[1]) == int(ts[2]) and int(ts[-1]) == 1
+    state = sch.make_state(x0)
+    x = x0.clone()
+    for i in range(sch.n_model_calls()):
+        sch.load_step(state, i)
+        x = sch.step(model(x, int(ts[i])), x, state)
+    assert float((x.double() - ref).norm() / ref.norm()) <= 2e-5
+
+
+def test_pndm_with_a_constant_model_output_is_ddim():
+    """every Adams-Bashforth combination of a constant is that constant, and PNDM's transfer is DDIM's deterministic update"""
+    from diffusion_pruning_amd.pipeline import DDIMSchedulerLite, PNDMSchedulerLite
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 8, 8, generator=g)
+    eps = torch.randn(1, 4, 8, 8, generator=g)
+    N = 25
+    pn, dd = PNDMSchedulerLite(prediction_type="epsilon"), DDIMSchedulerLite(prediction_type="epsilon")
+    pn.set_timesteps(N); dd.set_timesteps(N)
+    sp, sd = pn.make_state(x0), dd.make_state(x0)
+    xp = xd = x0
+    for i in range(pn.n_model_calls()):
+        pn.load_step(sp, i)
+        xp = pn.step(eps, xp, sp)
+    for i in range(dd.n_model_calls()):
+        dd.load_step(sd, i)
+        xd = dd.step(eps, xd, sd)
+    assert float((xp - xd).norm() / xd.norm()) <= 1e-5

@@ -184,3 +184,29 @@ def test_denoise_loop_hip_graph_matches_eager_and_oracle(tiny, cuda):
         u, c = noise.chunk(2)
         x = sch.step_coef(u + s * (c - u), sch.coef[i], x)
     assert rel_l2(out_g.float().cpu(), x) < 6e-2      # guidance amplifies the per-forward bf16 error; 4 steps accumulate
+
+
+def test_pndm_loop_and_graph_reuse_across_prompt_batches(tiny, cuda):
+    """PNDM / PLMS scheduler (the reference's image-generation default) in the captured-step loop: graph == eager; a second
+    prompt batch through the same expert re-uses the captured step (FID-generation use case) and still equals eager"""
+    from diffusion_pruning_amd.pipeline import PNDMSchedulerLite, PruningDenoiseLoop
+    cfg, model, params = tiny
+    model.set_structure(clone_mask(O.fixed_half_mask(cfg), cuda))
+    g = torch.Generator().manual_seed(6)
+    B, steps, s = 2, 5, 2.0
+    loop = PruningDenoiseLoop(model, scheduler=PNDMSchedulerLite())
+    graphs = []
+    for call in range(2):
+        lat = torch.randn(B, 4, 16, 16, generator=g).to(cuda)
+        cond = torch.randn(B, 77, cfg.cross_attention_dim, generator=g).to(cuda)
+        uncond = torch.randn(B, 77, cfg.cross_attention_dim, generator=g).to(cuda)
+        out_g = loop(cond, lat, steps, s, negative_prompt_embeds=uncond, use_graph=True).latents
+        graphs.append(loop._graph["graph"])
+        out_e = loop(cond, lat, steps, s, negative_prompt_embeds=uncond, use_graph=False).latents
+        torch.cuda.synchronize()
+        assert torch.isfinite(out_g).all()
+        assert rel_l2(out_g.float().cpu(), out_e.float().cpu()) < 1e-5
+    assert graphs[0] is graphs[1]                          # captured once
+    model.set_structure(clone_mask(O.ones_mask(cfg), cuda))      # another architecture code: the key changes, a new capture
+    loop(cond, lat, steps, s, negative_prompt_embeds=uncond, use_graph=True)
+    assert loop._graph["graph"] is not graphs[0]

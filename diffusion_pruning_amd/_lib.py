@@ -113,6 +113,18 @@ class GegluParams(Structure):
     ]
 
 
+class FfTailParams(Structure):
+    _fields_ = [
+        ("h", c_void_p), ("ldh", c_int64), ("x", c_void_p), ("ldx", c_int64), ("y", c_void_p), ("ldy", c_int64),
+        ("w1", c_void_p), ("b1", c_void_p), ("cs1", c_void_p), ("n1", c_int32), ("ld1", c_int32),
+        ("w2", c_void_p), ("b2", c_void_p), ("ld2", c_int32),
+        ("w3", c_void_p), ("b3", c_void_p), ("ld3", c_int32),
+        ("colstat", c_void_p), ("colstat_ld", c_int32),
+        ("M", c_int32), ("C", c_int32),
+        ("eps", c_float),
+    ]
+
+
 class WgradParams(Structure):
     _fields_ = [
         ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dw", c_void_p),
@@ -212,6 +224,8 @@ EXPORTS = [
     ("aptp_gate_bwd", c_int, [POINTER(GateBwdParams), c_void_p]),
     ("aptp_geglu", c_int, [POINTER(GegluParams), c_void_p]),
     ("aptp_depth_lerp", c_int, [POINTER(DepthLerpParams), c_void_p]),
+    ("aptp_ff_tail_supported", c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    ("aptp_ff_tail", c_int, [POINTER(FfTailParams), c_void_p]),
     ("aptp_conv_wgrad_supported", c_int, [POINTER(WgradParams)]),
     ("aptp_conv_wgrad_suggest_split", c_int, [POINTER(WgradParams)]),
     ("aptp_conv_wgrad", c_int, [POINTER(WgradParams), c_void_p]),

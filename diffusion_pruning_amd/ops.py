@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import UnetEpilogueParams, UnetPrologueParams
-from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams, WgradParams,
+from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams, WgradParams, FfTailParams,
                    GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
                    ColsumParams, LayerNormPgradParams)
 
@@ -678,6 +678,56 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (B, heads, Lq)
         p.lse = lse.data_ptr()
     _lib.check(lib.aptp_attention(ctypes.byref(p), _stream()), "aptp_attention")
+    return out
+
+
+# Fused transformer tail (aptp_ff_tail): LN3 -> GEGLU projection -> ff.net[2] + residual -> proj_out + residual as one kernel
+# per 64-token tile.  Worth it only where a row tile per CU fills the chip and the activations, not the weights, are the
+# bytes that matter: M >= FUSE_TAIL_MIN_ROWS (SD-2.1 level 64 at bs >= 4).  APTP_FUSE_TAIL=0 disables; APTP_FUSE_TAIL_MIN_ROWS
+# moves the threshold (tests exercise the kernel on small maps).
+FUSE_TAIL = os.environ.get("APTP_FUSE_TAIL", "1") != "0"
+FUSE_TAIL_MIN_ROWS = int(os.environ.get("APTP_FUSE_TAIL_MIN_ROWS", "16384"))
+
+
+def ff_tail_supported(h: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, pw3: PackedWeight) -> bool:
+    if not (FUSE_TAIL and h.is_cuda and h.dtype == torch.bfloat16 and pw1.geglu and pw1.ln_colsum is not None):
+        return False
+    B, L, C = h.shape
+    if B * L < FUSE_TAIL_MIN_ROWS or pw2.N != C or pw3.N != C or pw2.bias is None or pw3.bias is None or pw1.bias is None:
+        return False
+    return bool(_lib.load().aptp_ff_tail_supported(B * L, C, pw1.N, pw1.cin_pad, pw2.cin_pad, pw3.cin_pad))
+
+
+def ff_tail(h: torch.Tensor, x: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, pw3: PackedWeight, eps: float = 1e-5,
+            out: Optional[torch.Tensor] = None, colstats: bool = False) -> torch.Tensor:
+    """y = proj_out(h + ff2(GEGLU(LN(h) W1'))) + x on token tensors [B, L, C] (bf16, contiguous channels, uniform row stride);
+    pw1 = GEGLU projection packed with geglu=True and the LayerNorm folded in, pw2 = ff.net[2], pw3 = proj_out."""
+    lib = _lib.load()
+    B, L, C = h.shape
+    for t, nm in ((h, "h"), (x, "x")):
+        assert t.dtype == torch.bfloat16 and t.is_cuda and tuple(t.shape) == (B, L, C) and t.stride(2) == 1, nm
+    if out is None:
+        out = torch.empty(B, L, C, dtype=torch.bfloat16, device=h.device)
+    else:
+        _colstats_drop(out.unsqueeze(2))
+    assert tuple(out.shape) == (B, L, C) and out.dtype == torch.bfloat16 and out.stride(2) == 1
+    p = FfTailParams()
+    for name, t in (("h", h), ("x", x), ("y", out)):
+        _, _, _, ld = _rows(t)
+        assert B == 1 or t.stride(0) == L * ld, "rows must be uniformly strided"
+        setattr(p, name, t.data_ptr())
+        setattr(p, "ld" + name, ld)
+    p.w1, p.b1, p.cs1, p.n1, p.ld1 = pw1.w.data_ptr(), pw1.bias.data_ptr(), pw1.ln_colsum.data_ptr(), pw1.N, pw1.cin_pad
+    p.w2, p.b2, p.ld2 = pw2.w.data_ptr(), pw2.bias.data_ptr(), pw2.cin_pad
+    p.w3, p.b3, p.ld3 = pw3.w.data_ptr(), pw3.bias.data_ptr(), pw3.cin_pad
+    p.M, p.C, p.eps = B * L, C, eps
+    cstats = None
+    if colstats and COLSTATS and L >= COLSTATS_MIN_HW and L % 64 == 0:
+        cstats = torch.empty(B * L // 64, C, 2, dtype=torch.float32, device=h.device)
+        p.colstat, p.colstat_ld = cstats.data_ptr(), C
+    _lib.check(lib.aptp_ff_tail(ctypes.byref(p), _stream()), "aptp_ff_tail")
+    if cstats is not None:
+        _colstats_put(out.unsqueeze(2), cstats, 64)
     return out
 
 

@@ -879,6 +879,17 @@ class Transformer2DModelWidthGated(nn.Module):
         q = self._ln_linear(pl, h, st, 2, "a2_q", **gkw)
         kv = self._ctx_kv(encoder_hidden_states, pl, tb, dev)
         o = ops.attention(q, kv[..., :w], kv[..., w:2 * w], hl)
+        # --- feed-forward + proj_out: one kernel per 64-token tile where a row tile per CU fills the chip (ops.ff_tail)
+        soft_depth = self.depth_gated and d_hard is None
+        if FOLD_LN and not pl["ff_dense_gate"] and not soft_depth:
+            pw1 = pl.get("ff1_ln")
+            if pw1 is None:
+                pw1 = pl["ff1_ln"] = pl["ff1_ln_make"]()
+            if ops.ff_tail_supported(h, pw1, pl["ff2"], pl["proj_out"]):
+                h = ops.linear(o, pl["a2_o"], residual=h)
+                out = ops.ff_tail(h, x_tok, pw1, pl["ff2"], pl["proj_out"], 1e-5, out=None if dst is None else dst.reshape(B, P, C),
+                                  colstats=True)
+                return self._ret(_nchw(out.reshape(B, H, W, C) if dst is None else dst), return_dict)
         h, st = ops.linear(o, pl["a2_o"], residual=h, rowstats=FOLD_LN)
         # --- feed-forward
         gkw = {}
@@ -889,7 +900,7 @@ class Transformer2DModelWidthGated(nn.Module):
         h = ops.linear(f, pl["ff2"], residual=h)
         # --- proj_out + residual (+ depth lerp)
         dkw = {}
-        if self.depth_gated and d_hard is None:
+        if soft_depth:
             dkw = dict(depth=d_vec, depth_in=x_tok)
         out = ops.linear(h, pl["proj_out"], residual=x_tok, out=None if dst is None else dst.reshape(B, P, C), colstats=True, **dkw)
         return self._ret(_nchw(out.reshape(B, H, W, C) if dst is None else dst), return_dict)

@@ -286,6 +286,29 @@ typedef struct {
 int aptp_unet_prologue(const AptpUnetPrologueParams* p, aptp_stream_t stream);
 int aptp_unet_epilogue(const AptpUnetEpilogueParams* p, aptp_stream_t stream);
 
+/* Fused tail of a transformer block on the large-M levels (diffusers BasicTransformerBlock.norm3 -> ff (GEGLUGated +
+ * Linear, pdm/models/unet/blocks.py:41-50,121-129,821-823) -> "+ hidden_states", then Transformer2DModel.proj_out and its
+ * "+ residual", blocks.py:1294-1308) as ONE kernel per 64-token tile:
+ *   y = proj_out(h + ff2(GEGLU(LN3(h) W1'))) + x,   optionally with the column statistics of y for the next GroupNorm
+ * (colstat [M/64][colstat_ld][2] = per (64-row block, channel) (sum, sumsq) of the bf16 outputs: AptpGroupNormParams.colstats
+ * with rows_per_block = 64).  w1 = the GEGLU projection packed with the LayerNorm folded in and (value | gate) rows interleaved
+ * in blocks of 16 (ops.pack_weight(geglu=True, ln_gamma=, ln_beta=)), b1 its bias', cs1 its column sums; w2 = ff.net[2] packed
+ * [C][ld2]; w3 = proj_out packed [C][ld3].  Requires aptp_ff_tail_supported(...) != 0 (M % 64 == 0, C in {64..320} a multiple
+ * of 64, ld1 == ld3 == C, ld2 % 64 == 0, n1 % 32 == 0). */
+typedef struct {
+  const void* h; int64_t ldh;      /* bf16 [M, C]: the residual stream after the cross-attention */
+  const void* x; int64_t ldx;      /* bf16 [M, C]: the transformer's input (residual of proj_out) */
+  void* y; int64_t ldy;            /* bf16 [M, C] */
+  const void* w1; const float* b1; const float* cs1; int32_t n1, ld1;
+  const void* w2; const float* b2; int32_t ld2;
+  const void* w3; const float* b3; int32_t ld3;
+  float* colstat; int32_t colstat_ld;
+  int32_t M, C;
+  float eps;
+} AptpFfTailParams;
+int aptp_ff_tail_supported(int M, int C, int n1, int ld1, int ld2, int ld3);
+int aptp_ff_tail(const AptpFfTailParams* p, aptp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Backward path (data gradients + gate gradients; the U-Net weights are frozen in APTP's pruning step,
  * pdm/training/trainer.py:742,827-829).  Data gradients of convolutions / linears reuse aptp_conv_gemm with

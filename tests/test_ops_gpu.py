@@ -789,3 +789,62 @@ def test_bad_arguments_fail_loudly(ops, cuda):
     pw = ops.pack_weight(torch.zeros(8, 12, 3, 3), None, cin_pad_to=1, device=cuda)
     with pytest.raises((AptpError, ValueError)):
         ops.conv_gemm(x, pw)
+
+
+@pytest.mark.parametrize("B,L,C,inner,x_wide", [(2, 1024, 320, 640, 0), (1, 4096, 320, 1280, 320), (2, 256, 64, 256, 0),
+                                               (1, 1024, 128, 200, 0), (4, 64, 256, 1024, 0)])
+def test_ff_tail_fused_kernel(cuda, B, L, C, inner, x_wide):
+    """aptp_ff_tail: LN3 -> GEGLU projection -> ff.net[2] + residual -> proj_out + residual in one kernel per 64-token tile,
+    against (a) fp32 PyTorch on the same bf16 operands with the same bf16 rounding points and (b) the four separate launches;
+    inner = live hidden width (640 = the 50 % mask at level 64, 200 = an irregular expert: not a multiple of 64)."""
+    from diffusion_pruning_amd import ops
+    g = torch.Generator().manual_seed(C * 7 + inner)
+    M = B * L
+    hbuf = (torch.randn(B, L, C, generator=g) * 1.5).bfloat16()
+    xbuf = torch.randn(B, L, C + x_wide, generator=g).bfloat16()
+    ln_g, ln_b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    w1 = torch.randn(2 * inner, C, generator=g) / C ** 0.5
+    b1 = torch.randn(2 * inner, generator=g) * 0.1
+    w2 = torch.randn(C, inner, generator=g) / inner ** 0.5
+    b2 = torch.randn(C, generator=g) * 0.1
+    w3 = torch.randn(C, C, generator=g) / C ** 0.5
+    b3 = torch.randn(C, generator=g) * 0.1
+    # full-width GEGLU module with `inner` live units = what a compacted plan packs: rows [0, inner) of each half
+    pw1 = ops.pack_weight(w1, b1, geglu=True, device=cuda, ln_gamma=ln_g, ln_beta=ln_b)
+    pw1_plain = ops.pack_weight(w1, b1, geglu=True, device=cuda)
+    pw2 = ops.pack_weight(w2, b2, cin_pad_to=16, device=cuda)
+    pw3 = ops.pack_weight(w3, b3, device=cuda)
+    h, x = hbuf.to(cuda), xbuf.to(cuda)[..., :C]
+    old_min = ops.FUSE_TAIL_MIN_ROWS
+    ops.FUSE_TAIL_MIN_ROWS = 64
+    try:
+        assert ops.ff_tail_supported(h, pw1, pw2, pw3)
+        y = ops.ff_tail(h, x, pw1, pw2, pw3, 1e-5, colstats=True)
+    finally:
+        ops.FUSE_TAIL_MIN_ROWS = old_min
+    torch.cuda.synchronize()
+    # (a) fp32 reference with the kernel's rounding points (f and h3 are bf16; weights are bf16)
+    hf, xf = hbuf.float(), xbuf[..., :C].float()
+    bfw = lambda t: t.bfloat16().float()
+    n = F.layer_norm(hf, (C,), ln_g, ln_b, 1e-5)
+    w1f = bfw(w1 * ln_g[None, :])                                   # the fold rounds w * gamma to bf16
+    pre = (n - ln_b) / ln_g                                          # = (h - mean) * rstd
+    hg = pre @ w1f.t() + (b1 + w1 @ ln_b)
+    f = bfw(hg[..., :inner] * F.gelu(hg[..., inner:]))
+    h3 = bfw(f @ bfw(w2).t() + b2 + hf)
+    ref = h3 @ bfw(w3).t() + b3 + xf
+    assert rel_l2(y.float().cpu(), ref) <= 4e-3
+    # (b) the separate launches
+    nn_ = ops.layernorm(h, ln_g.to(cuda), ln_b.to(cuda), 1e-5)
+    ff = ops.linear(nn_, pw1_plain)
+    h3u = ops.linear(ff, pw2, residual=h)
+    yu = ops.linear(h3u, pw3, residual=x.contiguous())
+    assert rel_l2(y.float(), yu.float()) <= 4e-3
+    # column statistics of the stored bf16 values, one (sum, sumsq) per (64-row block, channel)
+    if L >= ops.COLSTATS_MIN_HW:
+        rec = ops._colstats_get(y.unsqueeze(2), C)
+        assert rec is not None and rec[0][1] == 64
+        st = rec[0][0].float().cpu()
+        yb = y.float().cpu().reshape(M // 64, 64, C)
+        assert torch.allclose(st[..., 0], yb.sum(1), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(st[..., 1], (yb * yb).sum(1), rtol=1e-4, atol=1e-2)

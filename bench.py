@@ -268,11 +268,13 @@ def run_infer(R: Rank):
         ms_per_step = elapsed / args.steps * 1e3
         value = R.world * args.steps / elapsed
         if R.rank == 0 and not R.cpu and not args.no_extras:
-            roofline = measure_roofline(ops, step, dev)
+            # (at N > 1 the other ranks wait for these legs in the final barrier: only the short ones run there)
+            roofline = measure_roofline(ops, step, dev, per_tile=R.world == 1)
             if L == 64:
                 flops = algorithmic_flops(not args.dense, B, L)
                 roofline["whole_step_tflops"] = round(flops / (ms_per_step * 1e-3) / 1e12, 1)
-            roofline["peak_measured"] = measure_peaks(ops, dev)
+            if R.world == 1:
+                roofline["peak_measured"] = measure_peaks(ops, dev)
             roofline_gn = measure_gn_roofline(ops, step, dev)
             if R.world == 1 and not args.no_cpu_baseline:
                 cpu_baseline = measure_cpu_baseline(model, args.dense)
@@ -397,7 +399,7 @@ def _time_graph(torch, stream, fn, reps=10):
         return e0.elapsed_time(e1) / reps
 
 
-def measure_roofline(ops, step, dev):
+def measure_roofline(ops, step, dev, per_tile: bool = True):
     """Device time of every conv_gemm launch of one forward (the dominant kernel family), measured with HIP events on
     the launch stream around a HIP graph that replays exactly those launches; then the same per kernel instantiation."""
     import torch
@@ -412,22 +414,22 @@ def measure_roofline(ops, step, dev):
         def fn():
             s = torch.cuda.current_stream().cuda_stream
             for rec in recs:
-                rc = lib.aptp_conv_gemm(ctypes.byref(rec["params"]), s)
+                rc = getattr(lib, rec.get("fn", "aptp_conv_gemm"))(ctypes.byref(rec["params"]), s)
                 assert rc == 0
         return fn
     total_ms = _time_graph(torch, stream, replayer(log))
     flops = sum(r["flops"] for r in log)
     n = len(log)
     achieved = flops / (total_ms * 1e-3) / 1e12
-    per_tile = {}
+    per_tile_out = {}
     groups = {}
     for r in log:
-        groups.setdefault(int(r["params"].tile), []).append(r)
-    for tile, recs in sorted(groups.items()):
+        groups.setdefault(r["fn"] if "fn" in r else int(r["params"].tile), []).append(r)
+    for tile, recs in (sorted(groups.items(), key=lambda kv: str(kv[0])) if per_tile else ()):
         ms = _time_graph(torch, stream, replayer(recs), reps=5)
         fl = sum(r["flops"] for r in recs)
         tf = fl / (ms * 1e-3) / 1e12
-        per_tile[str(tile)] = {"launches": len(recs), "ms": round(ms, 4), "tflops": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+        per_tile_out[str(tile)] = {"launches": len(recs), "ms": round(ms, 4), "tflops": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
     # HBM-side bytes per launch of this kernel family come from separate rocprofv3 --pmc passes over this same command
     # (FETCH_SIZE and WRITE_SIZE cannot share a pass; gfx950 FETCH_SIZE correction applied) committed under profiles/.
     traffic, traffic_src = None, None
@@ -441,10 +443,10 @@ def measure_roofline(ops, step, dev):
                            " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, bytes per launch)")
         except Exception:  # noqa: BLE001
             traffic = None
-    return {"bound": "mfma", "kernel": "conv_gemm family (implicit-GEMM conv/linear, all tile instantiations; per_tile keys = AptpTile ids of include/aptp_hip.h)",
+    return {"bound": "mfma", "kernel": "conv_gemm family (implicit-GEMM conv/linear, all tile instantiations, + aptp_ff_tail where it replaces three of them; per_tile keys = AptpTile ids of include/aptp_hip.h)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n, "avg_launch_us": round(total_ms * 1e3 / n, 2),
-            "family_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(flops / 1e9, 1), "per_tile": per_tile}
+            "family_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(flops / 1e9, 1), "per_tile": per_tile_out}
 
 
 def measure_gn_roofline(ops, step, dev):
@@ -547,6 +549,7 @@ def main(argv=None):
         if R.cpu:
             line["data"] = "DRYRUN on CPU with emulated ops and a tiny model: exercises launch/rendezvous/reporting only, NOT a measurement"
         print(json.dumps(line), flush=True)
+    R.barrier()                                   # ranks leave together (rank 0 ran the measurement legs meanwhile)
     R.finish()
 
 

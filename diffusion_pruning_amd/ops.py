@@ -728,6 +728,9 @@ def ff_tail(h: torch.Tensor, x: torch.Tensor, pw1: PackedWeight, pw2: PackedWeig
     _lib.check(lib.aptp_ff_tail(ctypes.byref(p), _stream()), "aptp_ff_tail")
     if cstats is not None:
         _colstats_put(out.unsqueeze(2), cstats, 64)
+    if LAUNCH_LOG is not None:       # same contraction work as the three aptp_conv_gemm launches it replaces: part of the family
+        LAUNCH_LOG.append({"params": p, "fn": "aptp_ff_tail", "flops": 2.0 * B * L * (C * pw1.N + pw2.Cin * C + C * C),
+                           "keep": (h, x, out, pw1, pw2, pw3, cstats)})
     return out
 
 

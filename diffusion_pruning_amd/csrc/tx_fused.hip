@@ -8,8 +8,11 @@
 //
 // Workgroup = 64 rows, 8 waves as 2 (rows) x 4 (columns).  LDS: the residual-stream tile H [C/64][64][64] bf16 in the
 // XOR-swizzled 128-byte-row image of conv_gemm (read as the MFMA activation operand, updated in place h2 -> h3), the GEGLU tile
-// F [2][64][64], a two-stage ring of weight tiles [rows][64] filled by LDS-DMA one tile ahead of the MFMAs, per-row LayerNorm
-// statistics.  Per hidden chunk of 128 units: K = C steps of the LN-folded, (h,g)-interleaved projection into a 64 x 256 fp32
+// F [2][64][64], a two-stage ring of weight tiles [rows][64], per-row LayerNorm statistics, the epilogue constants (bias',
+// column sums, biases).  The weight stream (1.4 MB per tile pass at level 64, re-read from L2 by every workgroup) is what bounds
+// this kernel: with ONE 32-40 KB tile in flight per CU and ~1.2 us from request to LDS it ran at 70 us per launch (= the three
+// launches it replaces); so the tiles are register-staged TWO ahead (two sets of 16-byte loads per thread: tile t+2 is requested
+// while tile t is multiplied and tile t+1 is written to its ring stage), which doubles the bytes in flight per CU.  Per hidden chunk of 128 units: K = C steps of the LN-folded, (h,g)-interleaved projection into a 64 x 256 fp32
 // tile (epilogue: rstd*(acc - mean*colsum) + bias, h*gelu(g) -> F), then two K-steps of ff.net[2] accumulate F x W2 into the
 // 64 x C fp32 tile that survives all chunks.  Then h3 = acc + b2 + h2 goes back into H, proj_out runs over it, and the tile
 // leaves through an fp32 staging image in the (now idle) ring: 16-byte coalesced x loads and y stores, column statistics of
@@ -19,8 +22,6 @@
 #include "aptp_common.h"
 
 namespace {
-
-__device__ uint4 g_zero_ff[16];                    // 256 B of zeros: the source of out-of-range weight rows / K columns
 
 struct FfK {
   const __bf16* h; int64_t ldh; const __bf16* x; int64_t ldx; __bf16* y; int64_t ldy;
@@ -51,7 +52,6 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   const int drow = tid >> 3;                                 // row of a 64-row DMA pass this lane fills
   const int schunk = (tid & 7) ^ ((drow >> 1) & 7);          // source chunk that lands in this lane's slot
-  const char* zpage = reinterpret_cast<const char*>(g_zero_ff) + schunk * 16;
 
   // ---- residual-stream tile -> H ---------------------------------------------------------------------------------------------
 #pragma unroll
@@ -61,24 +61,46 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
   }
 
   const int T1 = p.nchunks * (KC + 2), T = T1 + KC;
-  auto issue = [&](int t, int buf) {
-    const __bf16* W; int row0, k0, ld, nrows, kcols, R;
+  constexpr int NP = WROWS / 64;                             // 64-row passes of the largest tile = 16-byte loads per thread
+  struct TileSet { uint4 v[NP]; };
+  auto tile_geom = [&](int t, const __bf16*& W, int& row0, int& k0, int& ld, int& nrows, int& kcols, int& R) {
     if (t < T1) {
       const int ch = t / (KC + 2), u = t - ch * (KC + 2);
       if (u < KC) { W = p.w1; row0 = ch * 256; k0 = u * 64; ld = p.ld1; nrows = p.n1; kcols = p.ld1; R = 256; }
       else { W = p.w2; row0 = 0; k0 = ch * 128 + (u - KC) * 64; ld = p.ld2; nrows = C; kcols = p.ld2; R = C; }
     } else { W = p.w3; row0 = 0; k0 = (t - T1) * 64; ld = p.ld3; nrows = C; kcols = p.ld3; R = C; }
+  };
+  auto load_tile = [&](int t, TileSet& S) {                  // request: global -> registers (zeros outside the matrix)
+    const __bf16* W; int row0, k0, ld, nrows, kcols, R;
+    tile_geom(t, W, row0, k0, ld, nrows, kcols, R);
     const bool kok = k0 + schunk * 8 < kcols;
-    for (int i = 0; i * 64 < R; ++i) {
-      if (i * 64 + wave * 8 < R) {                           // wave-uniform
-        const int r = row0 + i * 64 + drow;
-        const char* src = (kok && r < nrows) ? reinterpret_cast<const char*>(W + (int64_t)r * ld + k0 + schunk * 8) : zpage;
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(ring + (buf * WROWS + i * 64 + wave * 8) * 64), 16, 0, 0);
-      }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int r = row0 + i * 64 + drow;
+      S.v[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (i * 64 < R && kok && r < nrows) S.v[i] = *reinterpret_cast<const uint4*>(W + (int64_t)r * ld + k0 + schunk * 8);
     }
   };
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  auto store_tile = [&](const TileSet& S, int t, int buf) {  // registers -> ring stage, in the swizzled image of the fragment reads
+    const int R = (t < T1 && (t % (KC + 2)) < KC) ? 256 : C;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (i * 64 < R) *reinterpret_cast<uint4*>(ring + (buf * WROWS + i * 64 + drow) * 64 + (tid & 7) * 8) = S.v[i];
+  };
+
+  // ---- epilogue constants -> LDS (read there by the epilogues: no vector-memory wait inside the loop) --------------------------
+  float* c_cs1 = stat + 128;                                 // [n1]
+  float* c_b1 = c_cs1 + p.n1;                                // [n1]
+  float* c_b2 = c_b1 + p.n1;                                 // [C]
+  float* c_b3 = c_b2 + C;                                    // [C]
+  for (int i = tid; i < p.n1; i += 512) { c_cs1[i] = p.cs1[i]; c_b1[i] = p.b1[i]; }
+  for (int i = tid; i < C; i += 512) { c_b2[i] = p.b2[i]; c_b3[i] = p.b3[i]; }
+
+  TileSet S0, S1;
+  load_tile(0, S0);
+  if (T > 1) load_tile(1, S1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the H tile's LDS-DMA and tile 0 / 1)
+  store_tile(S0, 0, 0);
   __syncthreads();
 
   // ---- LayerNorm statistics of the bf16 rows (8 threads per row) -------------------------------------------------------------
@@ -125,10 +147,13 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
     for (int j = 0; j < NF3; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int t = 0; t < T; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < T) issue(t + 1, (t + 1) & 1);
+  // iteration t: everyone is done with tile t-1 and sees tile t -> request tile t+2 into the set tile t came from -> multiply
+  // tile t -> write tile t+1 (requested during iteration t-1) into the stage tile t-1 occupied
+  auto iteration = [&](int t, TileSet& Sa, const TileSet& Sb) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < T) load_tile(t + 2, Sa);
     const int buf = t & 1;
     int ch = 0, u = 0;
     bool g1 = false, g2 = false;
@@ -158,8 +183,8 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
             const int nh = ch * 256 + wn * 64 + t2 * 32 + fq * 4, ng = nh + 16;
             float4 csh = {0, 0, 0, 0}, csg = {0, 0, 0, 0}, bh = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
             if (ng + 3 < p.n1) {
-              csh = *reinterpret_cast<const float4*>(p.cs1 + nh); csg = *reinterpret_cast<const float4*>(p.cs1 + ng);
-              bh = *reinterpret_cast<const float4*>(p.b1 + nh); bg = *reinterpret_cast<const float4*>(p.b1 + ng);
+              csh = *reinterpret_cast<const float4*>(c_cs1 + nh); csg = *reinterpret_cast<const float4*>(c_cs1 + ng);
+              bh = *reinterpret_cast<const float4*>(c_b1 + nh); bg = *reinterpret_cast<const float4*>(c_b1 + ng);
             }
             const float ch4[4] = {csh.x, csh.y, csh.z, csh.w}, cg4[4] = {csg.x, csg.y, csg.z, csg.w};
             const float bh4[4] = {bh.x, bh.y, bh.z, bh.w}, bg4[4] = {bg.x, bg.y, bg.z, bg.w};
@@ -201,7 +226,7 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
 #pragma unroll
           for (int j = 0; j < NF3; ++j) {
             const int n = wn * NC + j * 16 + fq * 4;
-            const float4 b = *reinterpret_cast<const float4*>(p.b2 + n);
+            const float4 b = *reinterpret_cast<const float4*>(c_b2 + n);
             __bf16* hp = img_ptr(H, m, n);
             union { uint2 u; __bf16 e[4]; } old;
             old.u = *reinterpret_cast<const uint2*>(hp);
@@ -214,6 +239,11 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
         }
       }
     }
+    if (t + 1 < T) store_tile(Sb, t + 1, (t + 1) & 1);
+  };
+  for (int t = 0; t < T; t += 2) {
+    iteration(t, S0, S1);
+    if (t + 1 < T) iteration(t + 1, S1, S0);
   }
 
   // ---- proj_out accumulators + bias -> fp32 staging image [64][C] in the idle ring ------------------------------------------------
@@ -225,7 +255,7 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
 #pragma unroll
     for (int j = 0; j < NF3; ++j) {
       const int n = wn * NC + j * 16 + fq * 4;
-      const float4 b = *reinterpret_cast<const float4*>(p.b3 + n);
+      const float4 b = *reinterpret_cast<const float4*>(c_b3 + n);
       float4 o; o.x = acc3[i][j][0] + b.x; o.y = acc3[i][j][1] + b.y; o.z = acc3[i][j][2] + b.z; o.w = acc3[i][j][3] + b.w;
       *reinterpret_cast<float4*>(stage + m * C + n) = o;
     }
@@ -275,14 +305,18 @@ __global__ __launch_bounds__(512) void ff_tail_kernel(const FfK p) {
 template <int NF3>
 int launch_ff(const FfK& k, hipStream_t s) {
   constexpr int C = 64 * NF3, WROWS = C > 256 ? C : 256;
-  const size_t lds = (size_t)(NF3 * 64 * 64 + 2 * 64 * 64 + 2 * WROWS * 64) * 2 + 64 * 2 * 4;
-  static bool once = false;
-  if (!once) {
+  const size_t lds = (size_t)(NF3 * 64 * 64 + 2 * 64 * 64 + 2 * WROWS * 64) * 2 + 64 * 2 * 4 + ((size_t)2 * k.n1 + 2 * C) * 4;
+  if (lds > 160 * 1024) {
+    aptp_set_error("ff_tail: %zu bytes of LDS needed (n1 = %d too wide for C = %d)", lds, k.n1, C);
+    return APTP_EINVAL;
+  }
+  static size_t reserved = 0;
+  if (lds > reserved) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ff_tail_kernel<NF3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       aptp_set_error("ff_tail: cannot reserve %zu bytes of LDS", lds);
       return APTP_ELAUNCH;
     }
-    once = true;
+    reserved = lds;
   }
   hipLaunchKernelGGL(ff_tail_kernel<NF3>, dim3(k.M / 64), dim3(512), lds, s, k);
   return APTP_OK;
@@ -293,7 +327,11 @@ int launch_ff(const FfK& k, hipStream_t s) {
 #define ALIGN16(p) (((uintptr_t)(p) % 16) == 0)
 
 extern "C" int aptp_ff_tail_supported(int M, int C, int n1, int ld1, int ld2, int ld3) {
-  return M > 0 && M % 64 == 0 && C % 64 == 0 && C >= 64 && C <= 320 && n1 > 0 && n1 % 32 == 0 && ld1 == C && ld3 == C && ld2 % 64 == 0 && ld2 * 2 >= n1;
+  if (!(M > 0 && M % 64 == 0 && C % 64 == 0 && C >= 64 && C <= 320 && n1 > 0 && n1 % 32 == 0 && ld1 == C && ld3 == C && ld2 % 64 == 0 && ld2 * 2 >= n1))
+    return 0;
+  const int wrows = C > 256 ? C : 256;
+  const long lds = (long)(C * 64 + 2 * 64 * 64 + 2 * wrows * 64) * 2 + 512 + (2L * n1 + 2 * C) * 4;
+  return lds <= 160 * 1024;
 }
 
 extern "C" int aptp_ff_tail(const AptpFfTailParams* p, aptp_stream_t stream) {

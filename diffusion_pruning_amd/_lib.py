@@ -129,8 +129,17 @@ class WgradParams(Structure):
     _fields_ = [
         ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dw", c_void_p),
         ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("N", c_int32), ("KH", c_int32), ("KW", c_int32),
-        ("split_m", c_int32),
+        ("split_m", c_int32), ("ld_dw", c_int32),
     ]
+
+
+class FoldRowsParams(Structure):
+    _fields_ = [("partials", c_void_p), ("out", c_void_p), ("R", c_int32), ("n_rows", c_int32), ("C", c_int32), ("ld_out", c_int32)]
+
+
+class PackDgradParams(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("N", c_int32), ("C", c_int32), ("taps", c_int32), ("src_ld", c_int32),
+                ("dst_ld", c_int32), ("dst_rows", c_int32)]
 
 
 class DepthLerpParams(Structure):
@@ -229,6 +238,8 @@ EXPORTS = [
     ("aptp_conv_wgrad_supported", c_int, [POINTER(WgradParams)]),
     ("aptp_conv_wgrad_suggest_split", c_int, [POINTER(WgradParams)]),
     ("aptp_conv_wgrad", c_int, [POINTER(WgradParams), c_void_p]),
+    ("aptp_fold_rows", c_int, [POINTER(FoldRowsParams), c_void_p]),
+    ("aptp_pack_dgrad", c_int, [POINTER(PackDgradParams), c_void_p]),
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),
     ("aptp_layernorm_bwd", c_int, [POINTER(LayerNormBwdParams), c_void_p]),
     ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),

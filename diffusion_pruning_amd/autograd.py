@@ -309,12 +309,11 @@ class ConvPFn(Function):
                     dx = dx.view(B, H2 // 2, 2, W2 // 2, 2, C).float().sum(dim=(2, 4)).to(torch.bfloat16)
             dx = dx.squeeze(2) if tokens else dx
         if ctx.needs_input_grad[1]:
-            g = ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups)            # [N, taps, Cx] fp32
-            if tuple(g.shape) == pshape:
-                dP = g
-            else:
-                dP = torch.zeros(pshape, dtype=torch.float32, device=g.device)
-                dP[:g.shape[0], :, :g.shape[2]] = g
+            cx = x.shape[-1]
+            # straight into the packed layout [N, taps, cin_pad]: the kernel (or the slab fold) writes the first Cx columns,
+            # the pad columns stay zero
+            dP = (torch.zeros if pshape[2] != cx else torch.empty)(pshape, dtype=torch.float32, device=dy.device)
+            ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups, out=dP)
         if has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy)[:pshape[0]]
         return dx, dP, db, None, None, None, None, None, None, (dy if ctx.needs_input_grad[9] else None)

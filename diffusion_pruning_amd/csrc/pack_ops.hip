@@ -1,0 +1,121 @@
+// Small data-movement kernels of the packed-parameter fine-tune step (packed_train.py), each replacing a chain of torch
+// kernels inside the captured graph:
+//   aptp_fold_rows   out[row][c] = sum_r in[r][row][c]   (fixed order: deterministic) -- the slab sum of a split weight
+//                    gradient written straight into the padded packed layout, and the chunk sums of bias / norm-affine
+//                    gradients (was: torch reduce kernels, 526 per step at 8 us);
+//   aptp_pack_dgrad  the data-gradient operand of a contraction from its forward operand: dst[c][taps-1-t][n] = src[n][t][c]
+//                    (180-degree rotated transpose, bf16 -> bf16) as one tiled transpose through LDS (was: flip + strided
+//                    copy, 6-9 ms per step over 350 weights).
+#include "aptp_common.h"
+
+namespace {
+
+struct FoldK { const float* in; float* out; int R, n_rows, C, ld_out; };
+
+// block = 32 column quads x 8 row slices: slice s sums rows s, s+8, ... (independent 16-byte loads in flight), the slices are
+// folded 0..7 through LDS: the order is fixed, the result does not depend on scheduling
+__global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) {
+  __shared__ float4 red[8][32];
+  const int64_t total = (int64_t)p.n_rows * p.C;
+  const int cq = threadIdx.x & 31, rs = threadIdx.x >> 5;
+  if ((p.C & 3) == 0) {
+    const int64_t e = ((int64_t)blockIdx.x * 32 + cq) << 2;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < total) {
+      int r = rs;
+      for (; r + 24 < p.R; r += 32) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.in + (int64_t)r * total + e);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.in + (int64_t)(r + 8) * total + e);
+        const float4 b2 = *reinterpret_cast<const float4*>(p.in + (int64_t)(r + 16) * total + e);
+        const float4 b3 = *reinterpret_cast<const float4*>(p.in + (int64_t)(r + 24) * total + e);
+        a.x += (b0.x + b1.x) + (b2.x + b3.x); a.y += (b0.y + b1.y) + (b2.y + b3.y);
+        a.z += (b0.z + b1.z) + (b2.z + b3.z); a.w += (b0.w + b1.w) + (b2.w + b3.w);
+      }
+      for (; r < p.R; r += 8) {
+        const float4 b = *reinterpret_cast<const float4*>(p.in + (int64_t)r * total + e);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+    }
+    red[rs][cq] = a;
+    __syncthreads();
+    if (rs == 0 && e < total) {
+      float4 t = red[0][cq];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) { const float4 b = red[q][cq]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+      const int64_t row = e / p.C, c = e - row * p.C;
+      float* o = p.out + row * p.ld_out + c;
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    }
+  } else {
+    const int64_t e = (int64_t)blockIdx.x * 32 + cq;
+    float a = 0.f;
+    if (e < total)
+      for (int r = rs; r < p.R; r += 8) a += p.in[(int64_t)r * total + e];
+    reinterpret_cast<float*>(red)[rs * 32 + cq] = a;
+    __syncthreads();
+    if (rs == 0 && e < total) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += reinterpret_cast<float*>(red)[q * 32 + cq];
+      const int64_t row = e / p.C;
+      p.out[row * p.ld_out + (e - row * p.C)] = t;
+    }
+  }
+}
+
+struct PackK { const __bf16* src; __bf16* dst; int N, C, taps, src_ld, dst_ld, dst_rows; };
+
+// grid (ceil(N/64), ceil(C/64), taps); tile: src rows n0..n0+63 (64 channels c0..c0+63 each) -> dst rows c0.., columns n0..
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const PackK p) {
+  __shared__ __bf16 tile[64][72];
+  const int tid = threadIdx.x, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, t = blockIdx.z;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i, r = id >> 3, ch = id & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    const int n = n0 + r, c = c0 + ch * 8;
+    if (n < p.N && c < p.src_ld) v = *reinterpret_cast<const uint4*>(p.src + ((int64_t)n * p.taps + t) * p.src_ld + c);
+    *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = v;
+  }
+  __syncthreads();
+  const int td = p.taps - 1 - t;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i, r = id >> 3, ch = id & 7;      // output row c0 + r, columns n0 + 8*ch ..
+    const int c = c0 + r, n = n0 + ch * 8;
+    if (c < p.dst_rows && n < p.dst_ld) {
+      union { uint4 q; __bf16 e[8]; } o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o.e[k] = (c < p.C && n + k < p.N) ? tile[ch * 8 + k][r] : (__bf16)0.0f;
+      *reinterpret_cast<uint4*>(p.dst + ((int64_t)c * p.taps + td) * p.dst_ld + n) = o.q;
+    }
+  }
+}
+
+}  // namespace
+
+#define ALIGN16(p) (((uintptr_t)(p) % 16) == 0)
+
+extern "C" int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->partials && p->out && p->R >= 1 && p->n_rows >= 1 && p->C >= 1 && p->ld_out >= p->C, "fold_rows: bad arguments");
+  APTP_CHECK((p->C & 3) != 0 || (ALIGN16(p->partials) && (((int64_t)p->n_rows * p->C) & 3) == 0), "fold_rows: alignment");
+  FoldK k{p->partials, p->out, p->R, p->n_rows, p->C, p->ld_out};
+  const int64_t total = (int64_t)p->n_rows * p->C;
+  const int64_t work = (p->C & 3) == 0 ? total / 4 : total;          // column quads (or single columns), 32 per block
+  const int64_t blocks = (work + 31) / 32;
+  APTP_CHECK(blocks < (1LL << 31), "fold_rows: grid too large");
+  hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}
+
+extern "C" int aptp_pack_dgrad(const AptpPackDgradParams* p, aptp_stream_t stream) {
+  APTP_CHECK(p && p->src && p->dst && p->N >= 1 && p->C >= 1 && p->taps >= 1, "pack_dgrad: bad arguments");
+  APTP_CHECK(p->src_ld % 8 == 0 && p->dst_ld % 8 == 0 && ALIGN16(p->src) && ALIGN16(p->dst) && p->dst_rows >= p->C && p->src_ld >= p->C
+             && p->dst_ld >= p->N, "pack_dgrad: layout");
+  PackK k{(const __bf16*)p->src, (__bf16*)p->dst, p->N, p->C, p->taps, p->src_ld, p->dst_ld, p->dst_rows};
+  dim3 grid((p->dst_ld + 63) / 64, (p->dst_rows + 63) / 64, p->taps);
+  hipLaunchKernelGGL(pack_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}

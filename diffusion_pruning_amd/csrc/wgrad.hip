@@ -28,6 +28,7 @@ struct WgK {
   const __bf16* x; int64_t ldx; const __bf16* dy; int64_t lddy; float* dw;
   int B, H, W, C, N, M, HW, split, nsteps, tiles_n, tiles_c;
   int Wt, R, hw2;      // halo geometry (3x3): tile width, rows per step, Wt + 2
+  int ldw;             // row length of dw's c dimension
 };
 
 constexpr int PITCH = 72;          // bf16 elements per LDS row (64 + 8: spreads the 4-row transposed blocks over the banks)
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   }
 
   // ---- store: lane owns c = cbase + 4*(lane/16) .. +3 of n = nbase + lane%16 -------------------------------------------------
-  float* out = p.dw + (int64_t)slice * p.N * TAPS * p.C;
+  float* out = p.dw + (int64_t)slice * p.N * TAPS * p.ldw;
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf) {
     const int n = n0 + wn * 32 + nf * 16 + (lane & 15);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         float4 o; o.x = acc[t][cf][nf][0]; o.y = acc[t][cf][nf][1]; o.z = acc[t][cf][nf][2]; o.w = acc[t][cf][nf][3];
-        *reinterpret_cast<float4*>(out + ((int64_t)n * TAPS + t) * p.C + c) = o;
+        *reinterpret_cast<float4*>(out + ((int64_t)n * TAPS + t) * p.ldw + c) = o;
       }
     }
   }
@@ -193,6 +194,8 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dw = p->dw;
   k.B = p->B; k.H = p->H; k.W = p->W; k.C = p->C; k.N = p->N; k.HW = p->H * p->W; k.M = p->B * k.HW;
   k.nsteps = (k.M + 31) / 32;
+  k.ldw = p->ld_dw ? p->ld_dw : p->C;
+  APTP_CHECK(k.ldw >= p->C && k.ldw % 4 == 0, "conv_wgrad: ld_dw");
   k.split = p->split_m > k.nsteps ? k.nsteps : p->split_m;
   APTP_CHECK(k.split == p->split_m, "conv_wgrad: split_m %d exceeds the %d K-steps", p->split_m, k.nsteps);
   k.tiles_n = (p->N + 63) / 64; k.tiles_c = (p->C + 63) / 64;

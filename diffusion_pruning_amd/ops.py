@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import UnetEpilogueParams, UnetPrologueParams
-from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams, WgradParams, FfTailParams,
+from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams, WgradParams, FfTailParams, FoldRowsParams, PackDgradParams,
                    GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
                    ColsumParams, LayerNormPgradParams)
 
@@ -785,6 +785,35 @@ def _rows(t: torch.Tensor):
     return B, L, C, (t.stride(1) if L > 1 else max(t.stride(1), C))
 
 
+def fold_rows(partials: torch.Tensor, n_rows: int, C: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[row, c] = sum_r partials[r, row, c] (fp32, fixed order); partials is [R, n_rows, C] contiguous; `out` may be a
+    [n_rows, ld >= C] buffer whose extra columns are left alone (the padded packed layout of a weight gradient)."""
+    lib = _lib.load()
+    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() % (n_rows * C) == 0
+    R = partials.numel() // (n_rows * C)
+    if out is None:
+        out = torch.empty(n_rows, C, dtype=torch.float32, device=partials.device)
+    o2 = out.reshape(n_rows, -1)
+    assert o2.dtype == torch.float32 and o2.stride(1) == 1 and o2.shape[1] >= C and (n_rows == 1 or o2.stride(0) == o2.shape[1])
+    p = FoldRowsParams()
+    p.partials, p.out, p.R, p.n_rows, p.C, p.ld_out = partials.data_ptr(), o2.data_ptr(), R, n_rows, C, o2.shape[1]
+    _lib.check(lib.aptp_fold_rows(ctypes.byref(p), _stream()), "aptp_fold_rows")
+    return out
+
+
+def pack_dgrad_from_packed(pw: PackedWeight, pwb: PackedWeight) -> PackedWeight:
+    """refresh the data-gradient operand `pwb` (ops.pack_weight_dgrad layout) from the forward operand `pw` of the same
+    weights, bf16 -> bf16, one launch"""
+    lib = _lib.load()
+    taps = pw.KH * pw.KW
+    p = PackDgradParams()
+    p.src, p.dst, p.N, p.C, p.taps = pw.w.data_ptr(), pwb.w.data_ptr(), pw.N, pw.Cin, taps
+    p.src_ld, p.dst_ld, p.dst_rows = pw.cin_pad, pwb.cin_pad, pwb.N
+    assert pwb.KH == pw.KH and pwb.N >= pw.Cin and pwb.cin_pad >= pw.N and pw.Cin2 == 0
+    _lib.check(lib.aptp_pack_dgrad(ctypes.byref(p), _stream()), "aptp_pack_dgrad")
+    return pwb
+
+
 def gate_bwd(dy: torch.Tensor, y0: torch.Tensor, gate: torch.Tensor, want_dgate: bool = True):
     """dx = dy * gate (expanded over channel groups, batch tiled), dgate [Bg, G] = sum dy*y0 (fp32).
     want_dgate=False: the forward gate multiply (dy := y0) -- the partials are not folded, dgate is None."""
@@ -908,7 +937,7 @@ def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: 
         p.pgrad_partial = part.data_ptr()
     _lib.check(lib.aptp_groupnorm_bwd(ctypes.byref(p), _stream()), "aptp_groupnorm_bwd")
     if want_pgrad:
-        pg = part.sum(dim=(0, 1))
+        pg = fold_rows(part.view(-1, 1, C * 2), 1, C * 2).view(C, 2)
         return dx, pg[:, 1].contiguous(), pg[:, 0].contiguous()
     return dx
 
@@ -923,7 +952,7 @@ def layernorm_pgrad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5):
     p = LayerNormPgradParams()
     p.x, p.ldx, p.dy, p.lddy, p.rows, p.C, p.eps, p.partial = x.data_ptr(), ldx, dy.data_ptr(), lddy, B * L, C, eps, part.data_ptr()
     _lib.check(lib.aptp_layernorm_pgrad(ctypes.byref(p), _stream()), "aptp_layernorm_pgrad")
-    pg = part.sum(dim=0)
+    pg = fold_rows(part.view(-1, 1, C * 2), 1, C * 2).view(C, 2)
     return pg[:, 1].contiguous(), pg[:, 0].contiguous()
 
 
@@ -938,7 +967,7 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     p = ColsumParams()
     p.x, p.ldx, p.rows, p.C, p.partial = x2.data_ptr(), (x2.stride(0) if rows > 1 else C), rows, C, part.data_ptr()
     _lib.check(lib.aptp_colsum(ctypes.byref(p), _stream()), "aptp_colsum")
-    return part.sum(dim=0)
+    return fold_rows(part, 1, C).view(C)
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -982,9 +1011,11 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional
 WGRAD_KERNEL = os.environ.get("APTP_WGRAD_KERNEL", "1") != "0"
 
 
-def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: Optional[int] = None):
+def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: Optional[int] = None,
+                  out: Optional[torch.Tensor] = None):
     """x [B,H,W,C], dy [B,H,W,N] (bf16, channels contiguous, uniform pixel stride) -> fp32 [N, KH*KW, C] or None when
-    the geometry is not handled by aptp_conv_wgrad"""
+    the geometry is not handled by aptp_conv_wgrad.  out: an fp32 [N, KH*KW, ld >= C] buffer (a packed-layout gradient) that
+    receives the result in its first C columns (the rest is left alone); returned instead of a fresh tensor."""
     lib = _lib.load()
     B, H, W, C = x.shape
     N = dy.shape[3]
@@ -996,10 +1027,18 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
     _check_act(x, "conv_wgrad x")
     _check_act(dy, "conv_wgrad dy")
     p.split_m = int(split_m) if split_m else lib.aptp_conv_wgrad_suggest_split(ctypes.byref(p))
-    slabs = torch.empty(p.split_m, N, KH * KW, C, dtype=torch.float32, device=x.device)
+    if out is not None:
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[:2]) == (N, KH * KW) and out.shape[2] >= C
+    if p.split_m == 1:
+        res = out if out is not None else torch.empty(N, KH * KW, C, dtype=torch.float32, device=x.device)
+        p.dw, p.ld_dw = res.data_ptr(), res.shape[2]
+        _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
+        return res
+    slabs = torch.empty(p.split_m, N * KH * KW, C, dtype=torch.float32, device=x.device)
     p.dw = slabs.data_ptr()
     _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
-    return slabs[0] if p.split_m == 1 else slabs.sum(dim=0)
+    res = fold_rows(slabs, N * KH * KW, C, out=out)
+    return res if out is not None else res.view(N, KH * KW, C)
 
 
 def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int) -> torch.Tensor:
@@ -1021,15 +1060,17 @@ def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int
     return cols.reshape(KH * KW * C, B * Ho * Wo)
 
 
-def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int = 1, pad: int = 0, ups: int = 0) -> torch.Tensor:
-    """Weight gradient of y = conv(x, w): returns fp32 [N, KH*KW, C] (the packed-weight order, unpadded).
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int = 1, pad: int = 0, ups: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight gradient of y = conv(x, w): returns fp32 [N, KH*KW, C] (the packed-weight order, unpadded), or `out` (fp32
+    [N, KH*KW, ld >= C], e.g. a zero-initialised packed-layout gradient) with the result in its first C columns.
     x [B,H,W,C] (or tokens [B,L,C] with KH=KW=1), dy [B,Ho,Wo,N] (or [B,L,N]); both bf16."""
     if x.dim() == 3:
         # tokens: one image of B*L x 1 "pixels" (a linear layer has no spatial structure)
         x, dy = x.reshape(1, -1, 1, x.shape[-1]), dy.reshape(1, -1, 1, dy.shape[-1])
     C, N = x.shape[-1], dy.shape[-1]
     if WGRAD_KERNEL and stride == 1 and ups == 0 and KH == KW and pad == KH // 2 and x.shape[:3] == dy.shape[:3]:
-        g = _wgrad_direct(x, dy, KH, KW)
+        g = _wgrad_direct(x, dy, KH, KW, out=out)
         if g is not None:
             return g
     xt = _im2col_T(x, KH, KW, stride, pad, ups)                   # [K, M]
@@ -1046,5 +1087,9 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     Np = round_up(N, 8)
     if Np != N:
         dyt = torch.nn.functional.pad(dyt, (0, 0, 0, Np - N))
-    out = conv_gemm(dyt.view(1, Np, 1, Mp), pw, pad=0, out_f32=True, prefetch=False)            # [1, Np, 1, Kp] fp32
-    return out.view(Np, Kp)[:N, :K].reshape(N, KH * KW, C)
+    res = conv_gemm(dyt.view(1, Np, 1, Mp), pw, pad=0, out_f32=True, prefetch=False)            # [1, Np, 1, Kp] fp32
+    res = res.view(Np, Kp)[:N, :K].reshape(N, KH * KW, C)
+    if out is not None:
+        out[:, :, :C] = res
+        return out
+    return res

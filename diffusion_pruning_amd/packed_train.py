@@ -66,8 +66,7 @@ class _Gemm:
 
     def refresh_bwd_(self):
         if self.pwb is not None:
-            N, C = self.pw.N, self.pw.Cin
-            self.pwb.w[:C, :, :N].copy_(self.pw.w[:, :, :C].flip(1).permute(2, 1, 0))
+            ops.pack_dgrad_from_packed(self.pw, self.pwb)          # one tiled transpose (was: flip + strided copy)
 
     @torch.no_grad()
     def export_(self):

@@ -378,10 +378,23 @@ typedef struct {
   const void* dy; int64_t lddy;    /* bf16 [B*H*W, N]: gradient of its output */
   float* dw;                       /* fp32 [split_m, N, KH*KW, C] */
   int32_t B, H, W, C, N, KH, KW, split_m;
+  int32_t ld_dw;                   /* row length of dw's innermost (c) dimension; 0 = C.  With split_m == 1 and ld_dw = cin_pad the
+                                      kernel writes straight into a packed-layout gradient (pad columns are not touched) */
 } AptpWgradParams;
 int aptp_conv_wgrad_supported(const AptpWgradParams* p);
 int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p);
 int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream);
+
+/* out[row][c] = sum over r < R of partials[r][row][c] (partials: fp32 [R][n_rows][C] contiguous; out: fp32 [n_rows][ld_out]); fixed order.
+ * The slab sum of a split weight gradient (written into the padded packed layout) and the chunk sums of bias / affine gradients. */
+typedef struct { const float* partials; float* out; int32_t R, n_rows, C, ld_out; } AptpFoldRowsParams;
+int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream);
+
+/* Data-gradient operand from the forward operand of the same contraction (both in packed bf16 layout):
+ * dst[c][taps-1-t][n] = src[n][t][c] for n < N, c < C, zero in the rest of dst's [dst_rows][taps][dst_ld] image.
+ * (ops.pack_weight_dgrad of the same weights, without going through the diffusers layout.) */
+typedef struct { const void* src; void* dst; int32_t N, C, taps, src_ld, dst_ld, dst_rows; } AptpPackDgradParams;
+int aptp_pack_dgrad(const AptpPackDgradParams* p, aptp_stream_t stream);
 
 /* GroupNorm(+SiLU) data gradient.  fwd_stats = the [B, nchunk, groups, 2] (sum, sumsq) partials the forward wrote into its
  * workspace (keep that buffer alive); workspace: fp32 [B, nchunk, groups, 2]. */

@@ -47,7 +47,8 @@ def test_ctypes_layout_matches_the_c_header():
                "AptpAttentionBwdParams": _lib.AttentionBwdParams, "AptpColsumParams": _lib.ColsumParams,
                "AptpLayerNormPgradParams": _lib.LayerNormPgradParams, "AptpDepthLerpParams": _lib.DepthLerpParams,
                "AptpWgradParams": _lib.WgradParams,
-               "AptpFfTailParams": _lib.FfTailParams}
+               "AptpFfTailParams": _lib.FfTailParams, "AptpFoldRowsParams": _lib.FoldRowsParams,
+               "AptpPackDgradParams": _lib.PackDgradParams}
     body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, cls in structs.items():
         body.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

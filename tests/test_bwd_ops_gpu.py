@@ -264,3 +264,24 @@ def test_conv_wgrad_reads_channel_slices_in_place(ops, cuda):
     got = ops._wgrad_direct(x, dy, 3, 3)
     ref = ops._wgrad_direct(x.contiguous(), dy, 3, 3)
     assert torch.equal(got, ref)
+
+
+def test_fold_rows_and_pack_dgrad_from_packed(ops, cuda):
+    """the two data-movement kernels of the packed fine-tune step: a fixed-order slab fold into a padded layout, and the
+    data-gradient operand rebuilt from the forward operand (== ops.pack_weight_dgrad of the same weights, bit for bit)"""
+    g = torch.Generator().manual_seed(1)
+    part = torch.randn(5, 7, 24, generator=g).to(cuda)
+    out = torch.full((7, 40), -1.0, device=cuda)
+    ops.fold_rows(part, 7, 24, out=out)
+    assert torch.allclose(out[:, :24], part.sum(0), atol=1e-5) and bool((out[:, 24:] == -1).all())
+    odd = torch.randn(3, 1, 10, generator=g).to(cuda)                     # C not a multiple of 4: scalar path
+    assert torch.allclose(ops.fold_rows(odd, 1, 10), odd.sum(0), atol=1e-6)
+    for (N, C, k) in [(72, 200, 3), (320, 136, 1), (8, 64, 3), (1280, 640, 1)]:
+        w = torch.randn(N, C, k, k, generator=g)
+        pw = ops.pack_weight(w, None, device=cuda)
+        want = ops.pack_weight_dgrad(pw.w[:, :, :pw.Cin].float().reshape(pw.N, k, k, pw.Cin).permute(0, 3, 1, 2), device=cuda)
+        got = ops.pack_weight_dgrad(torch.zeros(pw.N, pw.Cin, k, k), device=cuda)        # same shapes, zero content
+        got.w.fill_(7.0)
+        ops.pack_dgrad_from_packed(pw, got)
+        torch.cuda.synchronize()
+        assert got.w.shape == want.w.shape and torch.equal(got.w, want.w), (N, C, k)

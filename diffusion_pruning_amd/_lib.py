@@ -48,6 +48,8 @@ class ConvGemmParams(Structure):
         ("x2", c_void_p), ("ldx2", c_int64), ("Cin2", c_int32), ("cin2_pad", c_int32),
         ("prefetch", c_void_p), ("prefetch_bytes", c_int64),
         ("epilogue", c_int32),
+        ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_groups", c_int32), ("gn_C", c_int32), ("gn_silu", c_int32),
+        ("gn_eps", c_float),
     ]
 
 

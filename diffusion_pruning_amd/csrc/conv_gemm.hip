@@ -76,6 +76,7 @@ struct KParams {
   int epi16;                // 1: bf16 output (and residual / depth_in) rows are 16-byte aligned -> coalesced epilogue
   float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
   const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
+  const float* gn_gamma; const float* gn_beta; int gn_groups, gn_C, gn_silu; float gn_eps;   // reduce launch applies a GroupNorm
   FastDiv fd_hw, fd_wout;                    // / HW, / Wout (per lane)
   FastDiv fd_tm, fd_tn, fd_sk, fd_perm, fd_tmn;   // decode_block: / tiles_m, / tiles_n, / split_k, / (tiles_n * split_k), / (tiles_m * tiles_n)
 };
@@ -1626,6 +1627,96 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
   else epilogue_quad<false>(p, m, rc, n, h, h, st);
 }
 
+// Split-K reduce + the GroupNorm(+SiLU) that follows the convolution, for the small maps (AptpConvGemmParams.gn_gamma):
+// grid (groups, B); the workgroup owns the HW x cg column slab of its (sample, group): it sums the K-slices in slice order
+// (bit-identical to splitk_reduce_kernel), adds bias / rowbias, rounds to bf16, reduces (sum, sumsq) of the rounded values in a
+// fixed order, and writes the normalised activation.  Replaces splitk_reduce_kernel + gn_group_kernel (6 + 8 us on a level-16
+// map) and the round trip of the convolution output in between.
+constexpr int GN_RED_NT = 1024;            // 16 waves: only groups x B workgroups exist, so each must keep many loads in flight
+constexpr int GN_RED_QPT = 6;               // column quads per thread: HW * cg / 4 <= 6 * 1024
+__global__ __launch_bounds__(GN_RED_NT) void splitk_reduce_gn_kernel(const KParams p) {
+  __shared__ float red[2][GN_RED_NT];
+  __shared__ float stat[2];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cg = p.gn_C / p.gn_groups, qpr = cg >> 2;         // channels per group, quads per row
+  const int nquads = p.HW * qpr;
+  float v[GN_RED_QPT][4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN_RED_QPT; ++i) {
+    const int q = tid + GN_RED_NT * i;
+    if (q < nquads) {
+      const int r = q / qpr, n = g * cg + (q - r * qpr) * 4;
+      const int m = b * p.HW + r;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      // four slabs in flight per round trip; the adds stay in slice order (bit-identical to splitk_reduce_kernel)
+      for (int z0 = 0; z0 < p.split_k; z0 += 4) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int z = z0 + u < p.split_k ? z0 + u : z0;
+          t[u] = *reinterpret_cast<const float4*>(p.ws + ((int64_t)z * p.M + m) * p.ws_ld + n);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (z0 + u < p.split_k) { a[0] += t[u].x; a[1] += t[u].y; a[2] += t[u].z; a[3] += t[u].w; }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = a[e];
+        if (p.bias) x += p.bias[n + e];
+        if (p.rowbias) x += p.rowbias[(int64_t)b * p.ld_rowbias + n + e];
+        x = (float)(__bf16)x;                               // the value the separate launches would have stored
+        v[i][e] = x;
+        s1 += x; s2 += x * x;
+      }
+    }
+  }
+  red[0][tid] = s1; red[1][tid] = s2;
+  __syncthreads();
+  if (tid < 64) {                                             // fixed-order fold: 16 strided sums, then a 64-lane tree
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int w = 0; w < GN_RED_NT / 64; ++w) { a += red[0][tid + 64 * w]; c += red[1][tid + 64 * w]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); c += __shfl_xor(c, off); }
+    if (tid == 0) {
+      const float inv = 1.0f / ((float)cg * (float)p.HW);
+      const float mean = a * inv;
+      float var = c * inv - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      stat[0] = mean; stat[1] = rsqrtf(var + p.gn_eps);
+    }
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  __bf16* y = reinterpret_cast<__bf16*>(p.y);
+#pragma unroll
+  for (int i = 0; i < GN_RED_QPT; ++i) {
+    const int q = tid + GN_RED_NT * i;
+    if (q < nquads) {
+      const int r = q / qpr, n = g * cg + (q - r * qpr) * 4;
+      const int m = b * p.HW + r;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = (v[i][e] - mean) * rstd * p.gn_gamma[n + e] + p.gn_beta[n + e];
+        o[e] = p.gn_silu ? silu_f(z) : z;
+      }
+      uint2 pk; pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(y + (int64_t)m * p.ldy + n) = pk;
+    }
+  }
+  // pad columns [gn_C, N) of this sample (zero weights upstream, zero here): the last group's workgroup clears them
+  if (g == p.gn_groups - 1 && p.N > p.gn_C) {
+    const int padw = p.N - p.gn_C;
+    for (int e = tid; e < p.HW * padw; e += GN_RED_NT) {
+      const int r = e / padw, n = p.gn_C + (e - r * padw);
+      y[(int64_t)(b * p.HW + r) * p.ldy + n] = (__bf16)0.0f;
+    }
+  }
+}
+
 struct TileCfg { int bm, bn, wn, nw; };   // tile extents, the wave grid's N extent and the wave count (launch table below)
 const TileCfg kTiles[] = {
     {0, 0, 0, 0}, {128, 128, 2, 4}, {128, 160, 2, 4}, {64, 128, 2, 4}, {64, 160, 2, 4}, {128, 64, 2, 4},
@@ -1872,6 +1963,14 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   if (rc != APTP_OK) return rc;
   if (k.split_k > 1) APTP_CHECK(k.ws != nullptr && ((uintptr_t)k.ws % 16) == 0, "conv_gemm: split_k > 1 needs a 16B-aligned workspace");
   if (k.split_k == 1) k.counters = nullptr;
+  k.gn_gamma = p->gn_gamma; k.gn_beta = p->gn_beta; k.gn_groups = p->gn_groups; k.gn_C = p->gn_C; k.gn_silu = p->gn_silu; k.gn_eps = p->gn_eps;
+  if (k.gn_gamma) {
+    APTP_CHECK(k.gn_beta && k.split_k > 1 && !k.counters && !k.out_f32 && k.act == APTP_ACT_NONE && !k.colgate && !k.corr && !k.residual && !k.depth
+               && !k.rstat_out && !k.cstat_out && !k.ln_stats, "conv_gemm: gn_gamma needs a plain bf16 convolution split along K with a reduce launch");
+    APTP_CHECK(k.gn_groups > 0 && k.gn_C > 0 && k.gn_C <= k.N && k.gn_C % k.gn_groups == 0 && k.gn_C % 8 == 0 && (k.gn_C / k.gn_groups) % 4 == 0
+               && (int64_t)k.HW * (k.gn_C / k.gn_groups) <= 4LL * GN_RED_QPT * GN_RED_NT && k.ldy % 4 == 0,
+               "conv_gemm: gn_gamma geometry (C=%d groups=%d HW=%d)", k.gn_C, k.gn_groups, k.HW);
+  }
   hipStream_t s = (hipStream_t)stream;
   int t = pick_tile(p, k.M);
   if (t < 0 || t >= kNumTiles) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
@@ -1988,9 +2087,13 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   }
   APTP_LAUNCH_CHECK();
   if (k.split_k > 1 && !k.counters) {
-    const int quads = (k.act == APTP_ACT_GEGLU) ? k.N / 8 : k.N / 4;
-    const int64_t total = (int64_t)k.M * quads;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
+    if (k.gn_gamma) {
+      hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3(k.gn_groups, k.B), dim3(GN_RED_NT), 0, s, k);
+    } else {
+      const int quads = (k.act == APTP_ACT_GEGLU) ? k.N / 8 : k.N / 4;
+      const int64_t total = (int64_t)k.M * quads;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
+    }
     APTP_LAUNCH_CHECK();
   }
   return APTP_OK;

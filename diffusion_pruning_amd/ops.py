@@ -437,12 +437,19 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               depth: Optional[torch.Tensor] = None, depth_in: Optional[torch.Tensor] = None,
               out_f32: bool = False, split_k: Optional[int] = None, tile: int = 0, order: int = 0,
               rowstats: bool = False, ln=None, colstats: bool = False, x2: Optional[torch.Tensor] = None,
-              prefetch=None):
+              prefetch=None, gn=None):
     """y = epilogue(conv(x, w)); see include/aptp_hip.h for the epilogue order and the reference call sites.
+    gn = (gamma, beta, groups, eps, silu, C): return GroupNorm(+SiLU) of the convolution output over its first C channels
+    instead of the output itself.  On the small maps, where the launch is split along K anyway, the reduce launch of the
+    split applies the normalisation (AptpConvGemmParams.gn_gamma: one launch and one round trip less); otherwise this is
+    conv_gemm followed by ops.groupnorm.
     rowstats: also emit the per-row (sum, sumsq) partials of y a following folded LayerNorm needs; returns (y, stats)
     with stats fp32 [slots / 2, M, 4] (two (sum, sumsq) slots per element), or (y, None) when this launch is split along K (the caller then normalises with
     ops.layernorm).  ln = (stats, eps): x is the un-normalised input of a LayerNorm folded into pw (pack_weight ln_gamma)."""
     lib = _lib.load()
+    if gn is not None and (colgate is not None or act != ACT_NONE or pw.geglu or corr is not None or residual is not None
+                           or depth is not None or out_f32 or rowstats or ln is not None or out is not None):
+        raise ValueError("conv_gemm: gn= goes with a plain bf16 convolution (bias / rowbias only)")
     _check_act(x, "conv_gemm x")
     B, Hin, Win, Cx = x.shape
     if Cx != pw.Cin:
@@ -528,6 +535,15 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         split_k = lib.aptp_conv_gemm_suggest_split_k(ctypes.byref(p))
     p.split_k = max(1, int(split_k))
     ws = cnt = None
+    gn_fused = False
+    if gn is not None and FUSE_GN_REDUCE and p.split_k > 1 and Hout * Wout <= GN_REDUCE_MAX_HW:
+        gamma, beta, groups, eps_, silu_, Cn = gn
+        cgn = Cn // groups
+        gn_fused = Cn % 8 == 0 and Cn % groups == 0 and cgn % 4 == 0 and Hout * Wout * cgn <= 4 * 24 * 256 and Cn <= nout
+    if gn_fused:
+        in_kernel = False                  # the K-slices are combined by the reduce launch, which also normalises
+        colstats = False
+        p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_C, p.gn_silu, p.gn_eps = gamma.data_ptr(), beta.data_ptr(), groups, Cn, int(silu_), eps_
     if p.split_k > 1:
         if in_kernel is None:
             in_kernel = p.split_k <= 4 or explicit_split
@@ -576,7 +592,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         _colstats_put(out, cstats, rpb)
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * (pw.KH * pw.KW * pw.Cin + pw.Cin2),
-                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats, x2)})
+                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats, x2, gn)})
+    if gn is not None and not gn_fused:
+        gamma, beta, groups, eps_, silu_, Cn = gn
+        return groupnorm(out, gamma, beta, groups, eps_, silu_, C=Cn)
     return (out, stats) if rowstats else out
 
 
@@ -679,6 +698,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         p.lse = lse.data_ptr()
     _lib.check(lib.aptp_attention(ctypes.byref(p), _stream()), "aptp_attention")
     return out
+
+
+# GroupNorm applied by the reduce launch of a split-K convolution (conv_gemm(gn=...)) on maps of at most this many pixels
+# (SD-2.1 levels 16 and 8: norm2 + SiLU of the 12 resnets there).  Measured on MI355X: it TIES the separate launches
+# (187.3-187.7 vs 187.6 steps/s; 327 instead of 339 kernels per step): only groups x B = 64 workgroups exist, and their
+# 16 waves each stream the K-slices about as slowly as splitk_reduce_kernel on 256 CUs plus the single-launch GroupNorm take
+# together (a 256-thread version lost 3.8 %).  Off by default; APTP_FUSE_GN_REDUCE=1 turns it on (A/B timing, tests).
+FUSE_GN_REDUCE = os.environ.get("APTP_FUSE_GN_REDUCE", "0") != "0"
+GN_REDUCE_MAX_HW = 256
 
 
 # Fused transformer tail (aptp_ff_tail): LN3 -> GEGLU projection -> ff.net[2] + residual -> proj_out + residual as one kernel

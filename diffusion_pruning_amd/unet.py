@@ -428,8 +428,12 @@ class ResnetBlock2DWidthGated(nn.Module):
             gate_kw = dict(colgate=self._gate_dev(dev), gate_group=self.out_channels // self.groups)
         # (colstats: the GEMM that produces a GroupNorm input also emits its per-channel statistics; ops.groupnorm finds
         # them with the tensor and skips its own statistics pass on the large maps)
-        h = ops.conv_gemm(a1, pl["w1"], rowbias=rowbias, colstats=True, **gate_kw)
-        a2 = ops.groupnorm(h, pl["g2"], pl["b2"], pl["k_live"], self.eps, True, C=pl["c_live"])
+        if not gate_kw and H * W <= ops.GN_REDUCE_MAX_HW:
+            # small maps: conv1 is split along K, and the reduce launch of the split applies norm2 + SiLU (blocks.py:350-359)
+            a2 = ops.conv_gemm(a1, pl["w1"], rowbias=rowbias, gn=(pl["g2"], pl["b2"], pl["k_live"], self.eps, True, pl["c_live"]))
+        else:
+            h = ops.conv_gemm(a1, pl["w1"], rowbias=rowbias, colstats=True, **gate_kw)
+            a2 = ops.groupnorm(h, pl["g2"], pl["b2"], pl["k_live"], self.eps, True, C=pl["c_live"])
         dkw = {}
         if self.depth_gated and d_hard is None:
             dkw = dict(depth=d_vec, depth_in=x_in)

@@ -130,6 +130,17 @@ typedef struct {
   int64_t prefetch_bytes;
   int32_t epilogue;     /* 0 = auto (coalesced 16-byte stores through an LDS transpose when y / residual / depth_in rows are
                          * 16-byte aligned), 1 = force the accumulator-layout epilogue (testing / tuning) */
+  /* optional, small maps (Hout*Wout <= 256), split_k > 1 without tile_counters: the reduce launch of the split also applies
+   * the GroupNorm(+SiLU) that follows this convolution (ResnetBlock2D: conv1 + time_emb_proj -> norm2 -> SiLU,
+   * blocks.py:331-359): one workgroup per (sample, group) sums the K-slices of its Hout*Wout x (gn_C / gn_groups) columns,
+   * adds bias / rowbias, rounds to bf16 (the value the separate launches would have stored), takes the group's statistics,
+   * and writes y = act(gamma * (h - mean) * rstd + beta) -- y is then the NORMALISED tensor; the convolution output itself
+   * is never stored.  Needs act == NONE and no colgate / corr / residual / depth / statistics outputs, gn_C % 8 == 0,
+   * (gn_C / gn_groups) % 4 == 0; columns >= gn_C of y are written as zeros. */
+  const float* gn_gamma;  /* [gn_C] or NULL (= feature off) */
+  const float* gn_beta;
+  int32_t gn_groups, gn_C, gn_silu;
+  float gn_eps;
 } AptpConvGemmParams;
 
 enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TILE_64x128 = 3, APTP_TILE_64x160 = 4,

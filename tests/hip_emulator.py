@@ -24,7 +24,11 @@ def _bf(x):
 
 def conv_gemm(x, pw, *, stride=1, pad=None, ups=0, out=None, rowbias=None, colgate=None, gate_group=0, act=ACT_NONE,
               corr=None, residual=None, depth=None, depth_in=None, out_f32=False, split_k=None, tile=0,
-              rowstats=False, ln=None, colstats=False, x2=None, prefetch=None):
+              rowstats=False, ln=None, colstats=False, x2=None, prefetch=None, gn=None):
+    if gn is not None:
+        gamma, beta, groups, eps_, silu_, Cn = gn
+        h = conv_gemm(x, pw, stride=stride, pad=pad, ups=ups, rowbias=rowbias, split_k=split_k, tile=tile)
+        return groupnorm(h, gamma, beta, groups, eps_, silu_, C=Cn)
     B, H, W, C = x.shape
     assert C == pw.Cin and x.dtype == real_ops.ACT_DTYPE
     if pad is None:

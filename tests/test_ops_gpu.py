@@ -848,3 +848,38 @@ def test_ff_tail_fused_kernel(cuda, B, L, C, inner, x_wide):
         yb = y.float().cpu().reshape(M // 64, 64, C)
         assert torch.allclose(st[..., 0], yb.sum(1), rtol=1e-4, atol=1e-2)
         assert torch.allclose(st[..., 1], (yb * yb).sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,Cin,N,groups,live", [(4, 16, 1280, 640, 16, 640), (2, 8, 2560, 640, 16, 640), (1, 16, 640, 1280, 32, 1280),
+                                                   (2, 8, 320, 88, 11, 88), (2, 16, 128, 64, 16, 64)])
+def test_conv_with_groupnorm_in_the_splitk_reduce(cuda, B, H, Cin, N, groups, live):
+    """conv_gemm(gn=...): on the small maps the reduce launch of a split-K convolution also applies the GroupNorm(+SiLU) that
+    follows it (ResnetBlock2D conv1 + temb -> norm2 -> SiLU): same values as the two separate launches up to the group
+    statistics' summation order, and within the per-op tolerance of an fp32 reference."""
+    from diffusion_pruning_amd import ops
+    g = torch.Generator().manual_seed(Cin + N)
+    x = torch.randn(B, H, H, Cin, generator=g).bfloat16()
+    w = torch.randn(N, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    rb = torch.randn(B, N, generator=g) * 0.2
+    gamma, beta = torch.rand(live, generator=g) + 0.5, torch.randn(live, generator=g) * 0.1
+    pw = ops.pack_weight(w, b, device=cuda)
+    xd, rbd, gd, bd = x.to(cuda), rb.to(cuda).contiguous(), gamma.to(cuda), beta.to(cuda)
+    spec = (gd, bd, groups, 1e-5, True, live)
+    old = ops.FUSE_GN_REDUCE
+    try:
+        ops.FUSE_GN_REDUCE = True
+        ops.LAUNCH_LOG = []
+        fused = ops.conv_gemm(xd, pw, rowbias=rbd, gn=spec, split_k=4)
+        assert ops.LAUNCH_LOG[-1]["params"].gn_gamma                 # the reduce launch really carried the normalisation
+        ops.FUSE_GN_REDUCE = False
+        sep = ops.conv_gemm(xd, pw, rowbias=rbd, gn=spec, split_k=4)
+    finally:
+        ops.FUSE_GN_REDUCE, ops.LAUNCH_LOG = old, None
+    torch.cuda.synchronize()
+    assert fused.shape == sep.shape == (B, H, H, pw.N)
+    assert rel_l2(fused.float(), sep.float()) <= 2e-3
+    assert bool((fused[..., live:] == 0).all())
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1) + rb[:, :, None, None]
+    ref = F.silu(F.group_norm(y[:, :live].bfloat16().float(), groups, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    assert rel_l2(fused[..., :live].float().cpu(), ref) <= 6e-3

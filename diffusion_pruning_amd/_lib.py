@@ -156,6 +156,16 @@ class DepthLerpParams(Structure):
     ]
 
 
+class MseParams(Structure):
+    _fields_ = [
+        ("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64),
+        ("rows", c_int64), ("C", c_int32), ("f32", c_int32),
+        ("partial", c_void_p), ("out", c_void_p),
+        ("g", c_void_p), ("da", c_void_p), ("ldda", c_int64),
+        ("backward", c_int32),
+    ]
+
+
 class GroupNormBwdParams(Structure):
     _fields_ = [
         ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dx", c_void_p), ("lddx", c_int64),
@@ -242,6 +252,8 @@ EXPORTS = [
     ("aptp_conv_wgrad", c_int, [POINTER(WgradParams), c_void_p]),
     ("aptp_fold_rows", c_int, [POINTER(FoldRowsParams), c_void_p]),
     ("aptp_pack_dgrad", c_int, [POINTER(PackDgradParams), c_void_p]),
+    ("aptp_mse_nblocks", c_int, [c_int64, c_int32]),
+    ("aptp_mse", c_int, [POINTER(MseParams), c_void_p]),
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),
     ("aptp_layernorm_bwd", c_int, [POINTER(LayerNormBwdParams), c_void_p]),
     ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),

@@ -202,6 +202,29 @@ def depth_lerp(x_in: torch.Tensor, out: torch.Tensor, d: torch.Tensor) -> torch.
     return DepthLerpFn.apply(x_in, out, d)
 
 
+class MseFn(Function):
+    """F.mse_loss(a.float(), b.float(), reduction="mean") of the training steps' loss terms (trainer.py:1197-1225, 1729-1752)
+    on the operands as they are (bf16 activations, strided views, fp32 predictions): fp32 accumulation in a fixed order, the
+    gradient w.r.t. ``a`` in one launch, none w.r.t. ``b`` (the teacher side is always detached)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.mse(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return ops.mse_bwd(a, b, g), None
+
+
+def mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    assert not b.requires_grad, "mse: the second operand is the detached target"
+    if a.dtype != b.dtype:
+        a, b = a.float(), b.float()
+    return MseFn.apply(a, b)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Fine-tuning variants (SURVEY a20): the same ops with WEIGHT gradients.  The trainable tensors are the fp32 masters in
 # diffusers' layout; a pruned expert computes on compacted packs, so parameter gradients are produced in the compact

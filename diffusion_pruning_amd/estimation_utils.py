@@ -16,6 +16,75 @@ def sample_gumbel(shape, eps: float = 1e-20, fixed_seed: bool = False) -> torch.
     return -torch.log(eps - torch.log(u + eps))
 
 
+_GATHER_CACHE = {}
+
+
+def sample_gumbel_blocks(batch: int, widths, fixed_seed: bool = False, eps: float = 1e-20, device=None) -> torch.Tensor:
+    """cat([sample_gumbel((batch, w)) for w in widths], dim=1), bit for bit, from ONE host draw.
+
+    The CPU generator hands out its stream element by element, so k successive torch.rand calls equal one call of the total
+    length (tests/test_host_logic.py pins that); a cached gather index puts the values where the per-block calls would have
+    put them.  fixed_seed: every block restarts the seed-0 stream, i.e. block j holds the first batch*w_j values of it.
+    ~430 host-side tensor ops per call in the per-block form, 5 here.  On a GPU the uniforms travel through pinned memory
+    (a pageable copy would make the host wait for the stream)."""
+    widths = tuple(int(w) for w in widths)
+    key = (batch, widths, bool(fixed_seed))
+    idx = _GATHER_CACHE.get(key)
+    if idx is None:
+        cols, off = [], 0
+        for w in widths:
+            cols.append(off + torch.arange(batch)[:, None] * w + torch.arange(w)[None, :])
+            off += 0 if fixed_seed else batch * w
+        idx = _GATHER_CACHE[key] = torch.cat(cols, dim=1)
+    n = batch * (max(widths) if fixed_seed else sum(widths))
+    gen = torch.Generator().manual_seed(0) if fixed_seed else None
+    u = torch.rand(n, generator=gen)
+    if device is not None and torch.device(device).type == "cuda":
+        # the uniforms are the host stream; the transform runs on the device (5 launches).  On the host it is a handful of
+        # vectorised passes that ATen splits across OpenMP threads above 2,048 elements -- milliseconds each on a box whose
+        # visible cores exceed its CPU share -- and the result differs from the host's only in the last ulp of two logs.
+        dkey = key + (str(device),)
+        didx = _GATHER_CACHE.get(dkey)
+        if didx is None:
+            didx = _GATHER_CACHE[dkey] = idx.to(device)
+        u = _PinnedRing.of(key, u.shape).send(u, device)[didx]
+    else:
+        u = u[idx]
+    g = -torch.log(eps - torch.log(u + eps))
+    return g if device is None or g.device == torch.device(device) else g.to(device)
+
+
+class _PinnedRing:
+    """A few pinned staging buffers per noise shape, reused round-robin; an event per slot says when its last copy to the
+    device has finished (allocating pinned memory per call costs milliseconds, a pageable copy blocks on the stream)."""
+    SLOTS = 8
+    _rings = {}
+
+    @classmethod
+    def of(cls, key, shape):
+        r = cls._rings.get(key)
+        if r is None:
+            r = cls._rings[key] = cls(shape)
+        return r
+
+    def __init__(self, shape):
+        self.buf = [torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)]
+        self.ev = [None] * self.SLOTS
+        self.i = 0
+
+    def send(self, g, device):
+        i = self.i
+        self.i = (i + 1) % self.SLOTS
+        if self.ev[i] is not None:
+            self.ev[i].synchronize()
+        self.buf[i].copy_(g)
+        out = self.buf[i].to(device, non_blocking=True)
+        ev = self.ev[i] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.ev[i] = ev
+        return out
+
+
 def hard_concrete(out: torch.Tensor) -> torch.Tensor:
     """Straight-through threshold at 0.5 (estimation_utils.py:67-75): value {0,1}, gradient identity."""
     hard = (out >= 0.5).to(out.dtype)

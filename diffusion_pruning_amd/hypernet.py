@@ -11,6 +11,7 @@ import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.utils.parametrizations import weight_norm
 
 from .estimation_utils import hard_concrete
@@ -18,6 +19,20 @@ from .estimation_utils import hard_concrete
 
 def _flat(list_of_lists):
     return [v for sub in list_of_lists for v in sub]
+
+
+class _AliasCat(torch.autograd.Function):
+    """cat(parts, dim=0) where the parts already ARE consecutive row blocks of ``flat``: forward returns a view of flat,
+    backward hands every part its rows of the incoming gradient (views as well)"""
+
+    @staticmethod
+    def forward(ctx, flat, *parts):
+        ctx.sizes = [p.shape[0] for p in parts]
+        return flat.view_as(flat)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (None,) + tuple(grad.split(ctx.sizes, dim=0))
 
 
 class HyperStructure(nn.Module):
@@ -53,13 +68,57 @@ class HyperStructure(nn.Module):
     def forward(self, x):
         if self.single_arch_param:
             return self.arch          # one shared architecture for the whole batch (hypernet.py:66-68)
+        if self.fuse_heads:
+            return self._forward_fused(x)
         x = x.to(self.mh_fc[0].weight.device)
         return torch.cat([head(x) for head in self.mh_fc], dim=1)
 
-    def print_param_stats(self):
-        for name, param in self.named_parameters():
-            if "weight" in name:
-                print(f"{name}: {param.mean()}, {param.std()}")
+    # ---- the 71 heads as ONE GEMM ---------------------------------------------------------------------------------------
+    # cat_i(head_i(x)) = x @ cat_i(W_i)^T + cat_i(b_i)  (W_i = g_i * v_i / |v_i|_row under weight norm): the reference's loop
+    # is 2-5 launch-bound kernels per head forward and as many backward (~600 per step, a few ms of an otherwise
+    # graph-replayed pruning step).  The per-head Parameters stay what they are (names, shapes, state_dict:
+    # mh_fc.{i}.weight|bias, or mh_fc.{i}.parametrizations.weight.original{0,1}); their STORAGE is re-homed into one flat
+    # buffer per kind, and _AliasCat hands autograd the flat view forward / row slices backward, so neither direction copies.
+    fuse_heads = True
+
+    def _head_params(self):
+        if self.wn_flag:
+            kinds = {"v": [h.parametrizations.weight.original1 for h in self.mh_fc],
+                     "g": [h.parametrizations.weight.original0 for h in self.mh_fc]}
+        else:
+            kinds = {"v": [h.weight for h in self.mh_fc]}
+        if self.linear_bias:
+            kinds["b"] = [h.bias for h in self.mh_fc]
+        return kinds
+
+    def _flat_heads(self):
+        kinds = self._head_params()
+        flat = self.__dict__.get("_flat")
+        if flat is not None and flat.keys() == kinds.keys():
+            ok = True
+            for k, ps in kinds.items():
+                f = flat[k]
+                last = f.shape[0] - ps[-1].shape[0]
+                ok = ok and ps[0].data_ptr() == f.data_ptr() and ps[-1].data_ptr() == f[last:].data_ptr()
+            if ok:
+                return flat, kinds
+        flat = {}
+        with torch.no_grad():                      # first use, or the parameters were moved (.to / .cuda re-allocate them)
+            for k, ps in kinds.items():
+                f = torch.cat([p.data for p in ps], dim=0)
+                for p, c in zip(ps, f.split([p.shape[0] for p in ps], dim=0)):
+                    p.data = c
+                flat[k] = f
+        self.__dict__["_flat"] = flat
+        return flat, kinds
+
+    def _forward_fused(self, x):
+        flat, kinds = self._flat_heads()
+        W = _AliasCat.apply(flat["v"], *kinds["v"])
+        if self.wn_flag:
+            W = torch._weight_norm(W, _AliasCat.apply(flat["g"], *kinds["g"]), 0)   # parametrizations.weight_norm, dim=0
+        b = _AliasCat.apply(flat["b"], *kinds["b"]) if self.linear_bias else None
+        return F.linear(x.to(W.device), W, b)
 
     @staticmethod
     def _split(inputs, width_list, n_depth, force_width_non_zero=False):

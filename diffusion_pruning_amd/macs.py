@@ -308,3 +308,88 @@ def unet_get_block_utilization(model):
                 util.append(transformer_utilization(t))
         out.append(util)
     return out
+
+
+class VectorizedMacs:
+    """``unet_calc_macs`` as a handful of tensor operations on the ARCHITECTURE VECTOR itself (the [Bg, n_width + n_depth]
+    tensor whose column slices are the gates), for the pruning step: the module-walking form above -- the reference's
+    structure (blocks.py:384-416 ... unet_2d_conditional.py:2124-2163) -- issues ~15 tiny kernels per resnet and ~40 per
+    transformer, forward and again backward, ~2,000 launch-bound kernels per train step.  Same numbers:
+
+        cur_prunable = sum_j P_j r_j D_j + sum_k E_k d_k
+        cur_total    = sum_j P_j r_j D_j (detached) + sum over modules of (T - P) D (detached) + ungated rest
+
+    r_j = mean of hard_concrete over width segment j, d_k = hard_concrete of depth entry k, D_j = d_k of the module that owns
+    gate j if that module is depth-gated, else 1; P_j the prunable MACs behind gate j, E_k the non-prunable MACs of depth-gated
+    module k.  Built from the module constants after ``count_macs`` (same walk order as ``set_structure``)."""
+
+    def __init__(self, model, device=None):
+        assert getattr(model, "_macs_assigned", None), "call count_macs(latent_size) first"
+        ones = unet_calc_macs_constants(model)
+        self.total_macs, self.prunable_macs = ones["total_macs"], ones["prunable_macs"]
+        P, dmap, widths, E, rest_nd = [], [], [], [], 0.0
+        k = 0
+        for blk in list(model.down_blocks) + [model.mid_block] + list(model.up_blocks):
+            for b in list(blk.resnets) + list(blk.attentions):
+                is_res = hasattr(b, "conv1")
+                kk = -1
+                if b.depth_gated:
+                    kk = k
+                    k += 1
+                if is_res:
+                    subs = [(b.gate.width, b.prunable_macs)]
+                    rest = b.total_macs - b.prunable_macs
+                else:
+                    tb = b.transformer_blocks[0]
+                    subs = [(tb.attn1.gate.width, tb.attn1.prunable_macs), (tb.attn2.gate.width, tb.attn2.prunable_macs)]
+                    if tb.gated_ff:
+                        subs.append((tb.ff.net[0].gate.width, tb.ff.prunable_macs))
+                    rest = b.total_macs - b.prunable_macs
+                for w, pm in subs:
+                    widths.append(w); P.append(pm); dmap.append(kk)
+                if kk >= 0:
+                    E.append(rest)
+                else:
+                    rest_nd += rest
+        self.n_width, self.n_depth = sum(widths), k
+        fixed = self.total_macs - sum(b.total_macs for blk in list(model.down_blocks) + [model.mid_block] + list(model.up_blocks)
+                                      for b in list(blk.resnets) + list(blk.attentions))
+        self.const_total = float(fixed + rest_nd)            # samplers, head, tail, non-prunable parts of un-depth-gated modules
+        member = torch.zeros(self.n_width, len(widths))
+        s0 = 0
+        for j, w in enumerate(widths):
+            member[s0:s0 + w, j] = 1.0 / w
+            s0 += w
+        dm = torch.tensor(dmap, dtype=torch.long)
+        self.member = member
+        self.P = torch.tensor(P, dtype=torch.float32)
+        self.E = torch.tensor(E, dtype=torch.float32)
+        self.has_depth = dm >= 0
+        self.didx = dm.clamp(min=0)
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        for n in ("member", "P", "E", "has_depth", "didx"):
+            setattr(self, n, getattr(self, n).to(device))
+        return self
+
+    def __call__(self, arch: torch.Tensor):
+        """arch [Bg, n_width + n_depth] (what HyperStructure.transform_structure_vector splits) -> the dict of unet_calc_macs"""
+        assert arch.shape[1] == self.n_width + self.n_depth
+        hc = hard_concrete(arch)
+        r = hc[:, :self.n_width] @ self.member                                   # [Bg, n_gates]
+        d = hc[:, self.n_width:]                                                 # [Bg, n_depth]
+        D = torch.where(self.has_depth[None, :], d[:, self.didx], torch.ones_like(r))
+        cur_p = ((r * D) @ self.P + d @ self.E).unsqueeze(1)
+        Dd = D.detach()
+        cur_t = ((r.detach() * Dd) @ self.P + d.detach() @ self.E + self.const_total).unsqueeze(1)
+        return {"prunable_macs": self.prunable_macs, "total_macs": self.total_macs,
+                "cur_prunable_macs": cur_p, "cur_total_macs": cur_t}
+
+
+def unet_calc_macs_constants(model):
+    """total / prunable MACs of the model (module constants only; makes sure every module's lazily filled totals exist)"""
+    with torch.no_grad():
+        out = unet_calc_macs(model)
+    return {"total_macs": float(out["total_macs"]), "prunable_macs": float(out["prunable_macs"])}

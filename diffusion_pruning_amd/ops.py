@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import UnetEpilogueParams, UnetPrologueParams
-from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams, WgradParams, FfTailParams, FoldRowsParams, PackDgradParams,
+from ._lib import (ACT_GEGLU, ACT_NONE, ACT_SILU, AttentionBwdParams, AttentionParams, ConvGemmParams, DepthLerpParams, GateBwdParams, WgradParams, FfTailParams, FoldRowsParams, PackDgradParams, MseParams,
                    GegluParams, GroupNormBwdParams, GroupNormParams, LayerNormBwdParams, LayerNormParams,
                    ColsumParams, LayerNormPgradParams)
 
@@ -275,6 +275,29 @@ _N_SLABS = 16
 _counters_lock = threading.Lock()
 
 
+class scratch_domain:
+    """``with ops.scratch_domain("teacher"): ...`` -- launches issued (or CAPTURED) inside use their own split-K counters and
+    scratch buffers.  Scratch is keyed by the launching stream, which is enough for eager concurrency; but every
+    ``torch.cuda.graph`` capture runs on the same capture stream, so two graphs that will REPLAY concurrently on different
+    streams (the pruning step's teacher next to the student forward) must be captured under different domains."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "domain", None)
+        _tls.domain = self.name
+        return self
+
+    def __exit__(self, *exc):
+        _tls.domain = self.prev
+        return False
+
+
+def _domain():
+    return getattr(_tls, "domain", None)
+
+
 def _tile_counters(device):
     """Zero-initialised arrival counters of the split-K launches issued on the CURRENT stream (every launch leaves them
     zero).  One pool of _N_SLABS slabs per device, created on first use outside stream capture (a fill recorded into a
@@ -291,7 +314,7 @@ def _tile_counters(device):
             if pool is None:
                 pool = {"buf": torch.zeros(_N_SLABS, _N_COUNTERS, dtype=torch.int32, device=device), "slab": {}}
                 _counters[key] = pool
-    sid = torch.cuda.current_stream().cuda_stream
+    sid = (torch.cuda.current_stream().cuda_stream, _domain())
     i = pool["slab"].get(sid)
     if i is None:
         with _counters_lock:
@@ -326,7 +349,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): stream-ordered reuse, kernels on one stream serialise; forwards that
     run concurrently on different streams must not share split-K slabs or GroupNorm partials."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.is_current_stream_capturing(),
-           torch.cuda.current_stream().cuda_stream)
+           torch.cuda.current_stream().cuda_stream, _domain())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -811,6 +834,61 @@ def _rows(t: torch.Tensor):
         return t.shape[0], t.shape[1] * t.shape[2], t.shape[3], _ld(t)
     B, L, C = t.shape
     return B, L, C, (t.stride(1) if L > 1 else max(t.stride(1), C))
+
+
+def _mse_view(t: torch.Tensor):
+    """(tensor to keep alive, rows, C, ld) of an operand of aptp_mse: any tensor whose elements form rows of C contiguous
+    values at a constant row stride (contiguous tensors, channel slices of NHWC buffers); anything else is copied once."""
+    if t.is_contiguous():
+        n = t.numel()
+        C = t.shape[-1] if (t.dim() > 1 and t.shape[-1] % 8 == 0) else n
+        return t, n // C, C, C
+    if t.dim() >= 2 and t.stride(-1) == 1 and t.shape[-1] % 8 == 0:
+        ld = t.stride(-2)
+        ok = ld % 8 == 0 and ld >= t.shape[-1]
+        for d in range(t.dim() - 2, 0, -1):               # outer dimensions must collapse onto the row stride
+            ok = ok and t.stride(d - 1) == t.stride(d) * t.shape[d]
+        if ok:
+            return t, t.numel() // t.shape[-1], t.shape[-1], ld
+    return _mse_view(t.contiguous())
+
+
+def mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """mean((a - b)^2) as an fp32 device scalar: two launches, no copies, fixed summation order (csrc/loss_ops.hip)"""
+    lib = _lib.load()
+    assert a.shape == b.shape and a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float32) and a.is_cuda
+    a, rows, C, lda = _mse_view(a)
+    b, rows_b, C_b, ldb = _mse_view(b)
+    if (rows_b, C_b) != (rows, C):                         # different row shapes for the same elements: flatten both
+        a, rows, C, lda = _mse_view(a.contiguous().reshape(-1))
+        b, _, _, ldb = _mse_view(b.contiguous().reshape(-1))
+    assert C % 8 == 0, "aptp_mse needs a multiple of 8 elements per row"
+    nblk = lib.aptp_mse_nblocks(rows, C)
+    partial = torch.empty(nblk, dtype=torch.float32, device=a.device)
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    p = MseParams()
+    p.a, p.lda, p.b, p.ldb, p.rows, p.C, p.f32 = a.data_ptr(), lda, b.data_ptr(), ldb, rows, C, int(a.dtype == torch.float32)
+    p.partial, p.out, p.backward = partial.data_ptr(), out.data_ptr(), 0
+    _lib.check(lib.aptp_mse(ctypes.byref(p), _stream()), "aptp_mse")
+    return out
+
+
+def mse_bwd(a: torch.Tensor, b: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """d mean((a - b)^2) / da * g = (a - b) * 2 g / n, in a's dtype and shape (contiguous)"""
+    lib = _lib.load()
+    shape = a.shape
+    a, rows, C, lda = _mse_view(a)
+    b, rows_b, C_b, ldb = _mse_view(b)
+    if (rows_b, C_b) != (rows, C):
+        a, rows, C, lda = _mse_view(a.contiguous().reshape(-1))
+        b, _, _, ldb = _mse_view(b.contiguous().reshape(-1))
+    g = g.detach().to(torch.float32).reshape(1)
+    da = torch.empty(shape, dtype=a.dtype, device=a.device)
+    p = MseParams()
+    p.a, p.lda, p.b, p.ldb, p.rows, p.C, p.f32 = a.data_ptr(), lda, b.data_ptr(), ldb, rows, C, int(a.dtype == torch.float32)
+    p.g, p.da, p.ldda, p.backward = g.data_ptr(), da.data_ptr(), C, 1
+    _lib.check(lib.aptp_mse(ctypes.byref(p), _stream()), "aptp_mse(bwd)")
+    return da
 
 
 def fold_rows(partials: torch.Tensor, n_rows: int, C: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -20,7 +20,7 @@ import torch.distributed as dist
 from torch import nn
 
 from .dist_utils import _span
-from .estimation_utils import sample_gumbel, gumbel_softmax_sample, hard_concrete, importance_gumbel_softmax_sample
+from .estimation_utils import sample_gumbel, sample_gumbel_blocks, gumbel_softmax_sample, hard_concrete, importance_gumbel_softmax_sample
 
 
 class StructureVectorQuantizer(nn.Module):
@@ -134,9 +134,7 @@ class StructureVectorQuantizer(nn.Module):
         fixed = not self.training
         B = z_q.shape[0]
         # depth first, then the width segments: the order fixes the host-RNG stream in training mode
-        noise = [sample_gumbel((B, zd.shape[1]), fixed_seed=fixed)] + \
-                [sample_gumbel((B, w), fixed_seed=fixed) for w in self.width_list]
-        noise = torch.cat(noise, dim=1).to(z_q.device)
+        noise = sample_gumbel_blocks(B, [zd.shape[1]] + list(self.width_list), fixed_seed=fixed, device=z_q.device)
         nd, nwz = noise[:, :zd.shape[1]], noise[:, zd.shape[1]:]
         d_sorted = importance_gumbel_softmax_sample(zd, temperature=self.temperature, offset=self.base, fixed_seed=fixed,
                                                     noise=nd)

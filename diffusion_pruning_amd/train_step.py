@@ -24,6 +24,8 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import dist_utils
+from . import autograd as AG
+from . import ops
 from .dist_utils import _rank, _span, _world
 from .losses import ContrastiveLoss, ResourceLoss, compute_snr
 
@@ -185,6 +187,24 @@ class BucketedGradReducer:
         self.reset()
 
 
+def _mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """mean((a - b)^2) in fp32 with the gradient flowing into ``a`` only (b: target / teacher side).  On the GPU the HIP
+    reduction (autograd.MseFn: no fp32 copies, fixed order, safe inside replayed graphs); host tensors (the CPU suite's
+    emulated runs) take torch's."""
+    b = b.detach()
+    if a.is_cuda:
+        return AG.mse(a, b)
+    return F.mse_loss(a.float(), b.float(), reduction="mean")
+
+
+def _mse_per_sample(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[B] per-sample means (the min-SNR weighted diffusion loss, trainer.py:1203-1213)"""
+    if a.is_cuda:
+        return torch.stack([_mse(a[i], b[i]) for i in range(a.shape[0])])
+    d = F.mse_loss(a.float(), b.detach().float(), reduction="none")
+    return d.mean(dim=list(range(1, d.dim())))
+
+
 class PrunerStep:
     def __init__(self, unet, hyper_net, quantizer, cfg: Optional[PruningLossConfig] = None,
                  schedule: Optional[NoiseSchedule] = None):
@@ -248,18 +268,17 @@ class PrunerStep:
         student_acts = dict(self.block_activations)
 
         if cfg.snr_gamma is None:                                                               # :1197-1216
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+            loss = _mse(model_pred, target)
         else:
             snr = compute_snr(self.schedule, timesteps)
             if cfg.prediction_type == "v_prediction":
                 snr = snr + 1
             w = torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
-            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
-        distillation_loss = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")  # :1218
+            loss = (_mse_per_sample(model_pred, target) * w).mean()
+        distillation_loss = _mse(model_pred, full_pred)  # :1218
         block_loss = torch.zeros((), device=model_pred.device)
         for k in student_acts:                                                                  # :1220-1225
-            block_loss = block_loss + F.mse_loss(student_acts[k].float(), teacher_acts[k].detach().float(), reduction="mean")
+            block_loss = block_loss + _mse(student_acts[k], teacher_acts[k])
         block_loss = block_loss / len(student_acts)
 
         macs = self.unet.calc_macs()                                                            # :1227-1238
@@ -298,13 +317,13 @@ class GraphedPrunerStep(PrunerStep):
     backward, autograd glue).  Everything that touches the U-Net has static shapes, so it is captured once:
 
     * ``g_teacher``: the all-ones (dense) forward under no_grad -> ``full_pred`` and the 9 block activations;
-    * ``g_student``: forward with the architecture code read from STATIC gate buffers, the three U-Net loss terms
-      (min-SNR diffusion MSE, output distillation, block distillation: trainer.py:1197-1225) and the backward down to the
-      gradient of those terms w.r.t. every gate buffer.
+    * ``g_student``: forward with the architecture code read from STATIC gate buffers;
+    * ``g_student_bwd``: the three U-Net loss terms (min-SNR diffusion MSE, output distillation, block distillation:
+      trainer.py:1197-1225) and the backward down to the gradient of those terms w.r.t. every gate buffer.
 
-    Each step the router runs eagerly (it draws host-side Gumbel noise, quirk Q6, and is tiny), its 84 gate tensors are
-    copied into the static buffers, the graphs are replayed, and the chain rule is closed eagerly:
-    ``autograd.backward([router-only losses] + gate tensors, [None] + captured gate gradients)``.
+    Each step the router runs eagerly (it draws host-side Gumbel noise, quirk Q6, and is tiny), its architecture code is
+    copied into the static buffer the 84 gate views alias, the graphs are replayed, and the chain rule is closed eagerly:
+    ``autograd.backward([router-only losses, arch code], [None, captured gradient w.r.t. the code])``.
     Losses and router gradients equal the eager step's (tests/test_train_step_gpu.py)."""
 
     def __init__(self, *a, **k):
@@ -331,14 +350,13 @@ class GraphedPrunerStep(PrunerStep):
     def _unet_losses(self, model_pred, student_acts, full_pred, teacher_acts, w, target):
         cfg = self.cfg
         if cfg.snr_gamma is None:
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+            loss = _mse(model_pred, target)
         else:
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
-            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
-        distillation_loss = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")
+            loss = (_mse_per_sample(model_pred, target) * w).mean()
+        distillation_loss = _mse(model_pred, full_pred)
         block_loss = torch.zeros((), device=model_pred.device)
         for k in student_acts:
-            block_loss = block_loss + F.mse_loss(student_acts[k].float(), teacher_acts[k].detach().float(), reduction="mean")
+            block_loss = block_loss + _mse(student_acts[k], teacher_acts[k])
         block_loss = block_loss / len(student_acts)
         return loss, distillation_loss, block_loss
 
@@ -352,23 +370,33 @@ class GraphedPrunerStep(PrunerStep):
         B = st["noisy_latents"].shape[0]
         ones = torch.ones((B, self.quantizer.vq_embed_dim), device=dev)
         full = self.hyper_net.transform_structure_vector(ones)
-        proto = self.hyper_net.transform_structure_vector(ones)
-        gw = [t.detach().clone().requires_grad_(True) for t in proto["width"]]
-        gd = [t.detach().clone().requires_grad_(True) for t in proto["depth"]]
+        # ONE static buffer holds the student's architecture code; the 84 gate tensors the U-Net reads are autograd LEAVES
+        # whose storage is a column range of it (no autograd edge outside the captured region: a view node recorded on the
+        # legacy default stream would make the captured backward hop streams), so a step installs a new code with one copy,
+        # and the captured backward ends by concatenating the 84 gate gradients into one [B, 1634] tensor
+        ga = ones.clone()
+        proto = self.hyper_net.transform_structure_vector(ga)
+        gw = [t.detach().requires_grad_(True) for t in proto["width"]]
+        gd = [t.detach().requires_grad_(True) for t in proto["depth"]]
+        from .macs import VectorizedMacs
+        vmacs = VectorizedMacs(self.unet, device=dev)
 
         def teacher():
-            with torch.no_grad():
+            # own split-K counters / scratch: this graph replays NEXT TO the student's forward (ops.scratch_domain)
+            with torch.no_grad(), ops.scratch_domain("teacher"):
                 pred = self.unet(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
                 return pred, dict(self.block_activations)
 
-        def student(full_pred, teacher_acts):
+        def student_fwd():
             pred = self.unet(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
-            acts = dict(self.block_activations)
+            return pred, dict(self.block_activations)
+
+        def student_bwd(pred, acts, full_pred, teacher_acts):
             loss, dist, blk = self._unet_losses(pred, acts, full_pred, teacher_acts, st["snr_w"], st["target"])
             total = loss + cfg.distillation_weight * dist + cfg.block_weight * blk
             grads = torch.autograd.grad(total, gw + gd, allow_unused=True)
-            grads = [torch.zeros_like(t) if g is None else g for g, t in zip(grads, gw + gd)]
-            return loss.detach(), dist.detach(), blk.detach(), grads
+            grad = torch.cat([(torch.zeros_like(t) if g is None else g).reshape(B, -1) for g, t in zip(grads, gw + gd)], dim=1)
+            return loss.detach(), dist.detach(), blk.detach(), grad
 
         # warm-up on a side stream (allocator / plan caches), then capture: the module state at capture time decides what
         # is baked in, so the structure is installed right before each capture
@@ -378,20 +406,28 @@ class GraphedPrunerStep(PrunerStep):
             self.unet.set_structure({"width": list(full["width"]), "depth": list(full["depth"])})
             fp, ta = teacher()
             self.unet.set_structure({"width": list(gw), "depth": list(gd)})
-            student(fp, ta)
+            student_bwd(*student_fwd(), fp, ta)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
+        # THREE graphs.  The student's forward does not read the teacher (only the loss terms do), so it is its own graph:
+        # at replay it starts as soon as the router has produced the code, NEXT TO the teacher graph that has been running
+        # on the side stream since the batch arrived; the loss + backward graph joins the two.  Graphs that replay
+        # concurrently must not share a memory pool (a pool hands one capture's freed scratch to the next capture, which is
+        # only safe when replays are serialised in capture order): the teacher has its own, the two student graphs share one.
         self.unet.set_structure({"width": list(full["width"]), "depth": list(full["depth"])})
         g_teacher = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_teacher):
             full_pred, teacher_acts = teacher()
         self.unet.set_structure({"width": list(gw), "depth": list(gd)})
         g_student = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_student, pool=g_teacher.pool()):
-            loss, dist, blk, grads = student(full_pred, teacher_acts)
-        self._cap = dict(st=st, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, loss=loss, dist=dist, blk=blk,
-                         grads=grads, full_pred=full_pred, side=torch.cuda.Stream())
+        with torch.cuda.graph(g_student):
+            pred, acts = student_fwd()
+        g_student_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_student_bwd, pool=g_student.pool()):
+            loss, dist, blk, grad = student_bwd(pred, acts, full_pred, teacher_acts)
+        self._cap = dict(st=st, ga=ga, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
+                         loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs)
         return self
 
     # ---- one step -------------------------------------------------------------------------------------------------------
@@ -405,38 +441,36 @@ class GraphedPrunerStep(PrunerStep):
         arch_vector = self.quantizer.gumbel_sigmoid_trick(arch_vector)
         arch_wdn = self.quantizer.width_depth_normalize(arch_vector)
         text_all, arch_all = gather_with_local_grad(text_embeddings, arch_wdn)
-        sep = self.hyper_net.transform_structure_vector(arch_vector if pretrain else arch_vector_quantized)
+        arch_used = arch_vector if pretrain else arch_vector_quantized                          # trainer.py:1165-1168
         contrastive_loss = self.contrastive(text_all, arch_all)
-        pieces = list(sep["width"]) + list(sep["depth"])
 
-        # The teacher depends on the batch only: its graph replays on a side stream WHILE the router above (hundreds of
-        # launch-bound kernels of a few microseconds each, during which the GPU is mostly idle) is still being issued on
-        # this stream.  Order on the device: batch copies -> [teacher graph || router] -> student graph.
-        # (The copies were queued first thing in this step, see _stage_batch.)
-        # MAC accounting is differentiable in the gates (calc_macs family): feed it the router-connected tensors.  Done
-        # BEFORE the student replay is queued and without the host classification copy, so the host never waits on the graphs.
-        self.unet.set_structure({"width": list(sep["width"]), "depth": list(sep["depth"])}, prefetch_hosts=False)
-        macs = self.unet.calc_macs()
+        # The teacher depends on the batch only: its graph replays on a side stream WHILE the router above (launch-bound
+        # kernels of a few microseconds each, during which the GPU is mostly idle) is still being issued on this stream.
+        # Order on the device: batch copies -> [teacher graph || router] -> student graph.
+        # (The copies were queued first thing in this step, see _stage_batch_and_launch_teacher.)
+        # MAC accounting is differentiable in the gates (calc_macs family): VectorizedMacs evaluates it on the router-connected
+        # architecture vector directly (same numbers as unet.calc_macs() after set_structure, tests/test_macs_pinned.py) in
+        # ~10 kernels instead of ~2,000, before the student replay is queued, so the host never waits on the graphs.
+        macs = cap["vmacs"](arch_used)
         ratios = macs["cur_prunable_macs"] / self.unet.resource_info_dict["cur_prunable_macs"].squeeze()
         resource_loss = self.resource(ratios.mean())
         max_loss = 1.0 - torch.max(ratios)
         std_loss = -torch.std(ratios)
 
         with torch.no_grad():
-            for dst, src in zip(cap["gw"] + cap["gd"], pieces):
-                dst.copy_(src.reshape(dst.shape))
+            cap["ga"].copy_(arch_used)
+        cap["g_student"].replay()                                     # forward: needs the code only
         torch.cuda.current_stream().wait_stream(cap["side"])          # teacher outputs ready
-        cap["g_student"].replay()
+        cap["g_student_bwd"].replay()                                 # losses against the teacher + backward to the code
 
         router_loss = cfg.resource_weight * resource_loss + cfg.contrastive_weight * contrastive_loss \
             + cfg.std_weight * std_loss + cfg.max_weight * max_loss
         unet_loss = cap["loss"] + cfg.distillation_weight * cap["dist"] + cfg.block_weight * cap["blk"]
-        gate_grads = [g.reshape(p.shape) for g, p in zip(cap["grads"], pieces)]
         return {"loss": (router_loss.detach() + unet_loss).clone(), "diff_loss": cap["loss"].clone(),
                 "distillation_loss": cap["dist"].clone(), "block_loss": cap["blk"].clone(),
                 "contrastive_loss": contrastive_loss.detach(), "resource_loss": resource_loss.detach(),
                 "resource_ratio": ratios.mean().detach(), "arch_vector_quantized": arch_vector_quantized.detach(),
-                "_router_loss": router_loss, "_gate_tensors": pieces, "_gate_grads": gate_grads}
+                "_router_loss": router_loss, "_gate_tensors": [arch_used], "_gate_grads": [cap["grad"]]}
 
     def _stage_batch_and_launch_teacher(self, noisy_latents, timesteps, encoder_hidden_states, target):
         cap = self._cap
@@ -529,23 +563,22 @@ class FineTunerStep:
             full_pred = self.teacher(noisy_latents, timesteps, encoder_hidden_states).sample.detach()      # :1726-1727
         model_pred = self.student(noisy_latents, timesteps, encoder_hidden_states).sample                  # :1729
         if cfg.snr_gamma is None:
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+            loss = _mse(model_pred, target)
         else:
             snr = compute_snr(self.schedule, timesteps)
             if cfg.prediction_type == "v_prediction":
                 snr = snr + 1
             w = torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
-            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
+            loss = (_mse_per_sample(model_pred, target) * w).mean()
         diff_loss = loss.detach().clone()
         loss = loss * cfg.diffusion_weight
         block_loss = torch.zeros((), device=model_pred.device)
         if cfg.block_weight > 0:
             for k in self.acts_s:
-                block_loss = block_loss + F.mse_loss(self.acts_s[k].float(), self.acts_t[k].detach().float(), reduction="mean")
+                block_loss = block_loss + _mse(self.acts_s[k], self.acts_t[k])
             block_loss = block_loss / len(self.acts_s)
             loss = loss + cfg.block_weight * block_loss
-        distillation_loss = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")
+        distillation_loss = _mse(model_pred, full_pred)
         loss = loss + cfg.distillation_weight * distillation_loss
         return {"loss": loss, "diff_loss": diff_loss, "distillation_loss": distillation_loss.detach(),
                 "block_loss": block_loss.detach()}
@@ -585,19 +618,18 @@ class GraphedFineTunerStep(FineTunerStep):
     def _losses(self, model_pred, full_pred, w, target):
         cfg = self.cfg
         if cfg.snr_gamma is None:
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+            loss = _mse(model_pred, target)
         else:
-            loss = F.mse_loss(model_pred.float(), target.float(), reduction="none")
-            loss = (loss.mean(dim=list(range(1, loss.dim()))) * w).mean()
+            loss = (_mse_per_sample(model_pred, target) * w).mean()
         diff = loss.detach()
         total = loss * cfg.diffusion_weight
         blk = torch.zeros((), device=model_pred.device)
         if cfg.block_weight > 0:
             for k in self.acts_s:
-                blk = blk + F.mse_loss(self.acts_s[k].float(), self.acts_t[k].detach().float(), reduction="mean")
+                blk = blk + _mse(self.acts_s[k], self.acts_t[k])
             blk = blk / len(self.acts_s)
             total = total + cfg.block_weight * blk
-        dist_l = F.mse_loss(model_pred.float(), full_pred.float(), reduction="mean")
+        dist_l = _mse(model_pred, full_pred)
         total = total + cfg.distillation_weight * dist_l
         return total, diff, dist_l.detach(), blk.detach()
 

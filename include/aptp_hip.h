@@ -401,6 +401,22 @@ int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream);
 typedef struct { const float* partials; float* out; int32_t R, n_rows, C, ld_out; } AptpFoldRowsParams;
 int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream);
 
+/* Mean squared error of two equally shaped activations, read where they lie (the loss terms of Pruner.step / FineTuner.step:
+ * pdm/training/trainer.py:1197-1225 diffusion MSE, output distillation, block distillation; :1729-1752 for the fine-tune step).
+ * backward = 0: out[0] = mean((a - b)^2); partial: fp32 [aptp_mse_nblocks(rows, C)] scratch (every slot is written).
+ * backward = 1: da = (a - b) * g[0] * 2 / (rows * C)   (g: the fp32 device scalar dL/d(out); da has a's element type).
+ * f32 = 0: bf16 operands; f32 = 1: fp32 operands.  C multiple of 8; leading dimensions in elements, multiples of 8. */
+typedef struct {
+  const void* a; int64_t lda;
+  const void* b; int64_t ldb;
+  int64_t rows; int32_t C; int32_t f32;
+  float* partial; float* out;
+  const float* g; void* da; int64_t ldda;
+  int32_t backward;
+} AptpMseParams;
+int aptp_mse_nblocks(int64_t rows, int32_t C);
+int aptp_mse(const AptpMseParams* p, aptp_stream_t stream);
+
 /* Data-gradient operand from the forward operand of the same contraction (both in packed bf16 layout):
  * dst[c][taps-1-t][n] = src[n][t][c] for n < N, c < C, zero in the rest of dst's [dst_rows][taps][dst_ld] image.
  * (ops.pack_weight_dgrad of the same weights, without going through the diffusers layout.) */

@@ -285,3 +285,77 @@ def test_fold_rows_and_pack_dgrad_from_packed(ops, cuda):
         ops.pack_dgrad_from_packed(pw, got)
         torch.cuda.synchronize()
         assert got.w.shape == want.w.shape and torch.equal(got.w, want.w), (N, C, k)
+
+
+@pytest.mark.parametrize("case", ["bf16_nhwc", "bf16_slice", "f32_nchw", "bf16_big", "odd_rows"])
+def test_mse_matches_torch_fp64(cuda, case):
+    """ops.mse / autograd.MseFn (csrc/loss_ops.hip) vs F.mse_loss in fp64: value to fp32 summation accuracy, gradient to the
+    rounding of its own dtype; row-strided operands (a channel slice of a skip-concat buffer) are read in place."""
+    from diffusion_pruning_amd import autograd as AG
+    g = torch.Generator().manual_seed(3)
+    if case == "bf16_nhwc":
+        a = torch.randn(2, 16, 16, 320, generator=g).to(cuda, torch.bfloat16)
+        b = torch.randn(2, 16, 16, 320, generator=g).to(cuda, torch.bfloat16)
+    elif case == "bf16_slice":
+        buf = torch.randn(2, 8, 8, 640 + 320, generator=g).to(cuda, torch.bfloat16)
+        a = torch.randn(2, 8, 8, 640, generator=g).to(cuda, torch.bfloat16)
+        b = buf[..., :640]
+        assert not b.is_contiguous()
+    elif case == "f32_nchw":
+        a = torch.randn(4, 4, 64, 64, generator=g).to(cuda)
+        b = torch.randn(4, 4, 64, 64, generator=g).to(cuda)
+    elif case == "bf16_big":
+        a = (3 * torch.randn(4, 64, 64, 320, generator=g)).to(cuda, torch.bfloat16)
+        b = (3 * torch.randn(4, 64, 64, 320, generator=g)).to(cuda, torch.bfloat16)
+    else:
+        a = torch.randn(3, 5, 7, 24, generator=g).to(cuda, torch.bfloat16)
+        b = torch.randn(3, 5, 7, 24, generator=g).to(cuda, torch.bfloat16)
+    a1 = a.clone().requires_grad_()
+    a2 = a.clone().double().requires_grad_()
+    got = AG.mse(a1, b)
+    ref = F.mse_loss(a2, b.double())
+    assert got.dtype == torch.float32 and got.dim() == 0
+    assert abs(float(got) - float(ref)) <= 2e-6 * float(ref), (float(got), float(ref))
+    (got * 3.0).backward()
+    (ref * 3.0).backward()
+    assert a1.grad.dtype == a.dtype and a1.grad.shape == a.shape
+    assert rel_l2(a1.grad, a2.grad) <= (1e-6 if a.dtype == torch.float32 else 4e-3)
+    assert torch.equal(AG.mse(a1.detach(), b), got.detach())          # fixed summation order: same bits every call
+
+
+def test_mse_inside_replayed_graphs_matches_eager(cuda):
+    """the loss terms are captured into the train-step graphs: replaying must reproduce the eager value bit for bit, also
+    with another graph running on a second stream (torch's multi-block mse_loss reduction did not: tools/diag_overlap.py)"""
+    from diffusion_pruning_amd import autograd as AG
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(4, 64, 64, 320, generator=g).to(cuda, torch.bfloat16)
+    b = torch.randn(4, 64, 64, 320, generator=g).to(cuda, torch.bfloat16)
+    noise = torch.randn(1 << 22, device=cuda)
+
+    def busy():
+        y = noise
+        for _ in range(50):
+            y = y * 1.0001 + 1.0
+        return y
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        AG.mse(a, b); busy()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager = AG.mse(a, b).clone()
+    g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        out = AG.mse(a, b)
+    with torch.cuda.graph(g2):
+        keep = busy()
+    vals = []
+    for _ in range(16):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g2.replay()
+        g1.replay()
+        vals.append(out.clone())
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert all(torch.equal(v, eager) for v in vals)

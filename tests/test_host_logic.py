@@ -359,3 +359,58 @@ def test_pruned_semantics_is_exact_in_fp32(tiny_exact):
     assert rel_l2(out, ref) <= EXACT_TOL
     gated = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, clone_mask(mask)), "gated")
     assert rel_l2(out, gated) > 100 * EXACT_TOL        # ... and the two semantics really differ (the beta term)
+
+
+@pytest.mark.parametrize("wn,bias", [(True, False), (False, True), (True, True), (False, False)])
+def test_hypernet_heads_as_one_gemm_equal_the_per_head_loop(wn, bias):
+    """HyperStructure._forward_fused (parameters re-homed into flat storage, one weight-normalised GEMM) vs the reference's
+    per-head loop (hypernet.py:62-72): same outputs, same per-parameter gradients, same state_dict keys; the aliasing
+    survives optimizer steps, load_state_dict and deepcopy."""
+    import copy
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    st = {"width": [[32, 32], [5, 5, 20]], "depth": [[1, 1], [1]]}
+    torch.manual_seed(0)
+    h = HyperStructure(st, wn_flag=wn, linear_bias=bias)
+    if bias:
+        with torch.no_grad():
+            for hd in h.mh_fc:
+                hd.bias.normal_()
+    loop = copy.deepcopy(h)
+    loop.fuse_heads = False
+    x = torch.randn(4, 768)
+    a, b = h(x), loop(x)
+    assert float((a - b).abs().max()) <= 1e-6
+    a.square().sum().backward()
+    b.square().sum().backward()
+    for (n, p), (n2, p2) in zip(h.named_parameters(), loop.named_parameters()):
+        assert n == n2 and p.grad is not None
+        assert float((p.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max()) + 1e-12, n
+    assert list(h.state_dict().keys()) == list(loop.state_dict().keys())
+    o1, o2 = torch.optim.AdamW(h.parameters(), 1e-2), torch.optim.AdamW(loop.parameters(), 1e-2)
+    o1.step(); o2.step()
+    assert float((h(x) - loop(x)).abs().max()) < 1e-5
+    assert h._flat["v"].data_ptr() == h._head_params()["v"][0].data_ptr()
+    loop2 = HyperStructure(st, wn_flag=wn, linear_bias=bias)
+    h.load_state_dict(loop2.state_dict())
+    loop2.fuse_heads = False
+    assert float((h(x) - loop2(x)).abs().max()) <= 1e-6
+    assert float((copy.deepcopy(h)(x) - loop2(x)).abs().max()) <= 1e-6
+    h.double()                                       # re-allocates the parameters: the flat buffers are rebuilt
+    assert h(x.double()).dtype == torch.float64 and h._flat["v"].dtype == torch.float64
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_one_host_draw_equals_the_per_block_gumbel_draws(fixed):
+    """estimation_utils.sample_gumbel_blocks vs the reference's order of draws (quantizer.py:196-213: depth block, then one
+    torch.rand per width segment on the host generator): identical values AND the generator ends in the same state."""
+    from diffusion_pruning_amd.estimation_utils import sample_gumbel, sample_gumbel_blocks
+    widths = [14, 320, 320, 5, 1280, 17, 1]
+    for B in (1, 4):
+        torch.manual_seed(77)
+        ref = torch.cat([sample_gumbel((B, w), fixed_seed=fixed) for w in widths], dim=1)
+        after_ref = torch.rand(3)
+        torch.manual_seed(77)
+        got = sample_gumbel_blocks(B, widths, fixed_seed=fixed)
+        after_got = torch.rand(3)
+        assert torch.equal(ref, got)
+        assert torch.equal(after_ref, after_got)

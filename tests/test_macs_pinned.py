@@ -201,3 +201,42 @@ def test_total_decomposes_into_matmul_only_plus_convention_terms():
             out_side = (side - 1) // 2 + 1 if b.kind == "down" else side * 2
             extra += b.sampler_ch * out_side ** 2                   # sampler conv bias
     assert EXPECT["models"]["sd21_64"]["total_macs"] == O.count_macs(cfg, latent) + extra
+
+
+@pytest.mark.parametrize("which", ["tiny", "sd21"])
+def test_vectorized_macs_equals_the_module_walk(which):
+    """macs.VectorizedMacs (what the graphed pruning step evaluates, ~10 kernels) == unet.calc_macs() after set_structure
+    (the reference-shaped module walk), values and gradients, for soft per-sample codes."""
+    import torch
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    from diffusion_pruning_amd.macs import VectorizedMacs
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    from oracle import unet_oracle as O
+    if which == "tiny":
+        cfg, lat = O.TINY, 16
+        m = UNet2DConditionModelGated(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
+                                      cross_attention_dim=cfg.cross_attention_dim)
+    else:
+        cfg, lat = O.SD21, 64
+        m = UNet2DConditionModelGated()
+    m.set_structure(O.ones_mask(cfg))
+    m.count_macs(lat)
+    vm = VectorizedMacs(m)
+    st = m.get_structure()
+    g = torch.Generator().manual_seed(11)
+    A = torch.rand(3, vm.n_width + vm.n_depth, generator=g)
+    A[:, ::7] = 0.0                                   # closed channels; the hard-concrete forward is a step function
+    A[1, vm.n_width:] = 0.0                           # one sample with every depth gate closed
+    a1, a2 = A.clone().requires_grad_(), A.clone().requires_grad_()
+    sep = HyperStructure.transform_arch_vector(a2, st)
+    m.set_structure({"width": list(sep["width"]), "depth": list(sep["depth"])})
+    ref, got = m.calc_macs(), vm(a1)
+    assert got["total_macs"] == ref["total_macs"] and got["prunable_macs"] == ref["prunable_macs"]
+    for k in ("cur_prunable_macs", "cur_total_macs"):
+        assert got[k].shape == ref[k].shape
+        assert float(((got[k] - ref[k]).abs().max() / ref[k].abs().max()).detach()) < 1e-6, k
+    w = torch.tensor([[1.0], [2.0], [-0.5]])
+    (ref["cur_prunable_macs"] * w).sum().backward()
+    (got["cur_prunable_macs"] * w).sum().backward()
+    assert float((a1.grad - a2.grad).abs().max() / a2.grad.abs().max()) < 1e-6
+    assert not got["cur_total_macs"].requires_grad

@@ -186,3 +186,48 @@ def test_graphed_step_equals_eager_step(cuda):
             assert abs(float(out[k]) - v) <= tol * abs(v) + 1e-5, (i, k, float(out[k]), v)
         g = torch.cat([p_.grad.flatten() for p_ in hn.parameters()])
         assert rel_l2(g, g_ref) <= (1e-3 if i == 0 else 5e-2), (i, rel_l2(g, g_ref))
+
+
+def test_teacher_graph_next_to_student_forward_is_race_free(cuda):
+    """The teacher graph replays on a side stream WHILE the student's forward graph runs (GraphedPrunerStep.step).  Both were
+    captured on torch's one capture stream, so anything keyed by stream -- split-K arrival counters, split-K / GroupNorm
+    scratch -- would be shared; ops.scratch_domain gives the teacher its own.  SD-2.1 widths at 32x32 latents (split-K on
+    most GEMMs), 24 overlapped replays of one batch and one code with no host synchronisation in between: every replay must
+    reproduce the serialised result bit for bit."""
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+    from diffusion_pruning_amd.train_step import GraphedPrunerStep, synthetic_batch
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(cuda)
+    unet.freeze()
+    st = unet.get_structure()
+    torch.manual_seed(0)
+    hn = HyperStructure(structure=st, input_dim=768, wn_flag=False, linear_bias=True).to(cuda)
+    qz = StructureVectorQuantizer(n_e=8, structure=st, temperature=0.4, base=3, resource_aware_normalization=False,
+                                  optimal_transport=True).to(cuda)
+    step = GraphedPrunerStep(unet, hn, qz)
+    step.count_macs(32)
+    batch = synthetic_batch(2, 32, cuda, seed=5)
+    step.capture(batch)
+    cap = step._cap
+    g = torch.Generator().manual_seed(9)
+    cap["ga"].copy_((torch.rand(cap["ga"].shape, generator=g) * 0.6 + 0.4).to(cuda))
+
+    def replay(overlap: bool):
+        step._stage_batch_and_launch_teacher(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"],
+                                             batch["target"])
+        if not overlap:
+            torch.cuda.current_stream().wait_stream(cap["side"])
+        cap["g_student"].replay()
+        torch.cuda.current_stream().wait_stream(cap["side"])
+        cap["g_student_bwd"].replay()
+        return [cap[k].clone() for k in ("loss", "dist", "blk", "grad", "full_pred")]
+
+    ref = replay(overlap=False)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).all() for t in ref)
+    runs = [replay(overlap=True) for _ in range(24)]
+    torch.cuda.synchronize()
+    for r in runs:
+        for a, b in zip(r, ref):
+            assert torch.equal(a, b)

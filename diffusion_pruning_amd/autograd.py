@@ -244,10 +244,11 @@ class ConvWFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, pw: PackedWeight, get_bwd, stride: int, pad: int, ups: int, out_f32: bool,
-                live_out: Optional[torch.Tensor], live_in: Optional[torch.Tensor]):
+                live_out: Optional[torch.Tensor], live_in: Optional[torch.Tensor], rowbias: Optional[torch.Tensor] = None):
         tokens = x.dim() == 3
         xin = x.unsqueeze(2) if tokens else x
-        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32)
+        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32, rowbias=rowbias)
+        ctx.rowbias_shape = None if rowbias is None else tuple(rowbias.shape)
         ctx.save_for_backward(x, weight, bias if bias is not None else weight.new_zeros(0), live_out if live_out is not None else
                               torch.zeros(0, dtype=torch.long, device=x.device),
                               live_in if live_in is not None else torch.zeros(0, dtype=torch.long, device=x.device))
@@ -289,12 +290,22 @@ class ConvWFn(Function):
                 dW = g.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = _scatter_rows(bias, ops.colsum(dy)[:n_live], live_out if has_lo else None)
-        return dx, dW, db, None, None, None, None, None, None, None, None
+        drb = _rowbias_grad(dy, ctx.rowbias_shape) if (ctx.rowbias_shape is not None and ctx.needs_input_grad[11]) else None
+        return dx, dW, db, None, None, None, None, None, None, None, None, drb
 
 
-def conv_w(x, wparam, bparam, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None):
+def conv_w(x, wparam, bparam, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None, rowbias=None):
     pad = pw.KH // 2 if pad is None else pad
-    return ConvWFn.apply(x, wparam, bparam, pw, get_bwd, stride, pad, ups, out_f32, live_out, live_in)
+    return ConvWFn.apply(x, wparam, bparam, pw, get_bwd, stride, pad, ups, out_f32, live_out, live_in, rowbias)
+
+
+def _rowbias_grad(dy: torch.Tensor, shape) -> torch.Tensor:
+    """gradient of the per-sample output bias (the time-embedding projection added by conv1's epilogue, blocks.py:470-476):
+    per-sample column sums of dy, fp32, fixed order (colsum + fold kernels; a torch .sum over 4096 pixels per output may
+    take the multi-block path that misbehaves inside replayed graphs, see csrc/loss_ops.hip)"""
+    B, N = shape
+    g = torch.stack([ops.colsum(dy[b]) for b in range(dy.shape[0])])
+    return g[:, :N].contiguous()
 
 
 class ConvPFn(Function):
@@ -302,13 +313,14 @@ class ConvPFn(Function):
     [N][taps][cin_pad]; ``pw`` is its bf16 shadow.  dW comes out of the weight-gradient kernel in that order: no scatter."""
 
     @staticmethod
-    def forward(ctx, x, P, Pb, pw: PackedWeight, get_bwd, stride: int, pad: int, ups: int, out_f32: bool, residual):
+    def forward(ctx, x, P, Pb, pw: PackedWeight, get_bwd, stride: int, pad: int, ups: int, out_f32: bool, residual, rowbias=None):
         tokens = x.dim() == 3
         xin = x.unsqueeze(2) if tokens else x
         res = None
         if residual is not None:
             res = residual.unsqueeze(2) if tokens else residual
-        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=res)
+        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=res, rowbias=rowbias)
+        ctx.rowbias_shape = None if rowbias is None else tuple(rowbias.shape)
         ctx.save_for_backward(x)
         ctx.meta = (pw, get_bwd, stride, pad, ups, tokens, tuple(P.shape), Pb is not None)
         return y.squeeze(2) if tokens else y
@@ -339,12 +351,13 @@ class ConvPFn(Function):
             ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups, out=dP)
         if has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy)[:pshape[0]]
-        return dx, dP, db, None, None, None, None, None, None, (dy if ctx.needs_input_grad[9] else None)
+        drb = _rowbias_grad(dy, ctx.rowbias_shape) if (ctx.rowbias_shape is not None and ctx.needs_input_grad[10]) else None
+        return dx, dP, db, None, None, None, None, None, None, (dy if ctx.needs_input_grad[9] else None), drb
 
 
-def conv_p(x, P, Pb, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, residual=None):
+def conv_p(x, P, Pb, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, residual=None, rowbias=None):
     pad = pw.KH // 2 if pad is None else pad
-    return ConvPFn.apply(x, P, Pb, pw, get_bwd, stride, pad, ups, out_f32, residual)
+    return ConvPFn.apply(x, P, Pb, pw, get_bwd, stride, pad, ups, out_f32, residual, rowbias)
 
 
 class GroupNormWFn(Function):

@@ -124,12 +124,13 @@ class PackedTrainer:
 
     # ---- called by the model's fine-tuning forward in place of AG.conv_w / AG.GroupNormWFn / AG.LayerNormWFn -----------------
     def conv(self, x, weight, bias, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None,
-             residual=None):
+             residual=None, rowbias=None):
         e = self.gemms.get(id(weight))
         if e is None:
             e = self.gemms[id(weight)] = _Gemm(weight, bias, pw, live_out, live_in)
         assert e.pw is pw, "the plan's packs were rebuilt under a packed trainer (call PackedTrainer after the last set_structure)"
-        return AG.conv_p(x, e.P, e.Pb, e.pw, e.get_bwd, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=residual)
+        return AG.conv_p(x, e.P, e.Pb, e.pw, e.get_bwd, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=residual,
+                         rowbias=rowbias)
 
     def groupnorm(self, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live):
         a = self.affines.get(id(gamma_p))

@@ -130,6 +130,14 @@ def _take_dst(mod, B: int, H: int, W: int, C: int, device) -> Optional[torch.Ten
     return d[0].view(d[1], B, H, W, C, device)
 
 
+def _rowbias_of(tproj: torch.Tensor, n: int) -> torch.Tensor:
+    """[B, n_live] fp32 projection -> the [B, N] (pack-padded) per-sample bias conv_gemm reads"""
+    tproj = tproj.float()
+    if tproj.shape[1] >= n:
+        return tproj[:, :n]
+    return torch.nn.functional.pad(tproj, (0, n - tproj.shape[1]))
+
+
 def _cw(mod, x, weight, bias, pw, get_bwd, **kw):
     """weight-gradient convolution of the fine-tuning path: diffusers-layout masters (AG.conv_w) or, under a PackedTrainer
     (packed_train.py), the packed masters"""
@@ -393,9 +401,10 @@ class ResnetBlock2DWidthGated(nn.Module):
         emb_silu = temb.emb_silu if isinstance(temb, TembBundle) else torch.nn.functional.silu(temb.float()).to(torch.bfloat16)
         tproj = _cw(self, emb_silu[None], self.time_emb_proj.weight, self.time_emb_proj.bias, pl["temb_pw"],
                           self._sel_bwd_pack(pl, "temb", self.time_emb_proj.weight, dev, live), pad=0, out_f32=True, live_out=live)[0]
+        # the projection rides in conv1's epilogue as a per-sample output bias (one rounding, as in the inference path);
+        # its gradient is the per-sample column sum of conv1's output gradient
         h = _cw(self, a1, self.conv1.weight, self.conv1.bias, pl["w1"], self._sel_bwd_pack(pl, "w1", self.conv1.weight, dev, live),
-                      live_out=live)
-        h = (h.float() + tproj[:, None, None, :]).to(torch.bfloat16)
+                      live_out=live, rowbias=_rowbias_of(tproj, pl["w1"].N))
         a2 = _gnw(self, h, self.norm2.weight, self.norm2.bias, pl["g2"], pl["b2"], pl["k_live"], self.eps, True,
                                    pl["c_live"], live)
         sc = x

@@ -566,10 +566,14 @@ extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream
   k.c = p->scale * 1.44269504088896340736f;
   k.lse = p->lse;
   dim3 grid((p->Lq + 127) / 128, p->heads, p->B);
-  // split the key range over two wave groups when the query-parallel grid alone gives < 2 waves per SIMD
+  // Two key-range wave groups (8 waves) when the query-parallel grid alone gives < 2 waves per SIMD, and -- whatever the
+  // occupancy -- on long key ranges, where the double-buffered form (one barrier per key tile) wins even on a full chip
+  // (dense SD-2.1 level 64, B=4, 5 heads: 168 vs 183 us; masked, 2 heads: 64-68 vs 91 us; tools/bench_attn.py).
+  // An explicit variant forces its kernel.
   const int64_t waves = (int64_t)grid.x * grid.y * grid.z * 4;
   const int ntiles = (p->Lk + 63) / 64;
-  if (ntiles >= 2 && waves < 2 * 1024) {
+  const bool two_groups = ntiles >= 2 && p->variant != 5 && (waves < 2 * 1024 || ntiles >= 32 || p->variant != 0);
+  if (two_groups) {
     // The staggered form measured 5-10 % SLOWER than the lock-step one on MI355X (level-64 self-attention of SD-2.1:
     // 75.9 vs 69.3 us; tools/bench_attn.py), so it is opt-in only.
     if (p->variant == 1) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, k);     // staggered groups

@@ -265,7 +265,8 @@ typedef struct {
                     * K/V; measured slower than the lock-step form, kept for testing / A-B timing); 2 = force four key-range
                     * groups (16 waves); 3 = force two lock-step groups with single-buffered K/V (two barriers per key tile);
                     * 4 = force two lock-step groups with double-buffered K/V (one barrier per key tile; auto from 32 key
-                    * tiles) */
+                    * tiles); 5 = force the 4-wave kernel (one group).  An explicit variant overrides the occupancy rule
+                    * that otherwise chooses between one and two groups */
 } AptpAttentionParams;
 
 int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream);

@@ -24,14 +24,14 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) * 1e3 / (5 * reps)
 
 
-for (B, h, Lq, Lk) in [(4, 2, 4096, 4096), (4, 5, 1024, 1024), (4, 10, 256, 256), (4, 2, 4096, 77), (4, 5, 1024, 77), (4, 5, 4096, 4096)]:
+for (B, h, Lq, Lk) in [(4, 2, 4096, 4096), (4, 5, 1024, 1024), (4, 10, 256, 256), (4, 2, 4096, 77), (4, 5, 1024, 77), (4, 5, 4096, 4096), (4, 10, 1024, 1024), (4, 20, 256, 256), (4, 5, 4096, 77)]:
     q = torch.randn(B, Lq, h * 64, device=dev).bfloat16()
     k = torch.randn(B, Lk, h * 64, device=dev).bfloat16()
     v = torch.randn(B, Lk, h * 64, device=dev).bfloat16()
     o = ops.attention(q, k, v, h)
     fl = 4.0 * B * h * Lq * Lk * 64
     row = []
-    for var, name in ((3, "2 groups"), (2, "4 groups"), (1, "staggered"), (4, "dbuf"), (0, "auto")):
+    for var, name in ((3, "2 groups"), (2, "4 groups"), (1, "staggered"), (4, "dbuf"), (5, "1 group"), (0, "auto")):
         ops.ATTN_VARIANT = var
         t = timeit(lambda: ops.attention(q, k, v, h, out=o))
         row.append(f"{name} {t:6.1f} us {fl / t / 1e6:6.1f} TF")

@@ -836,9 +836,18 @@ def _rows(t: torch.Tensor):
     return B, L, C, (t.stride(1) if L > 1 else max(t.stride(1), C))
 
 
-def _mse_view(t: torch.Tensor):
-    """(tensor to keep alive, rows, C, ld) of an operand of aptp_mse: any tensor whose elements form rows of C contiguous
-    values at a constant row stride (contiguous tensors, channel slices of NHWC buffers); anything else is copied once."""
+def _mse_order(t: torch.Tensor):
+    """dimension order that sorts t's strides descending (ties by position): the permutation under which a permuted view --
+    the NCHW face of a channels-last activation -- becomes row-major again"""
+    return tuple(sorted(range(t.dim()), key=lambda d: (-t.stride(d), d)))
+
+
+def _mse_view(t: torch.Tensor, order=None):
+    """(tensor to keep alive, rows, C, ld) of an operand of aptp_mse: any tensor whose elements, taken in dimension order
+    `order`, form rows of C contiguous values at a constant row stride (contiguous tensors, NCHW faces of NHWC activations,
+    channel slices of NHWC buffers); anything else is copied once."""
+    if order is not None and order != tuple(range(t.dim())):
+        t = t.permute(order)
     if t.is_contiguous():
         n = t.numel()
         C = t.shape[-1] if (t.dim() > 1 and t.shape[-1] % 8 == 0) else n
@@ -853,16 +862,22 @@ def _mse_view(t: torch.Tensor):
     return _mse_view(t.contiguous())
 
 
+def _mse_operands(a: torch.Tensor, b: torch.Tensor):
+    order = _mse_order(a)
+    a2, rows, C, lda = _mse_view(a, order)
+    b2, rows_b, C_b, ldb = _mse_view(b, order)
+    if (rows_b, C_b) != (rows, C):                         # different row shapes for the same elements: flatten both
+        a2, rows, C, lda = _mse_view(a2.contiguous().reshape(-1))
+        b2, _, _, ldb = _mse_view(b2.contiguous().reshape(-1))
+    assert C % 8 == 0, "aptp_mse needs a multiple of 8 elements per row"
+    return order, a2, b2, rows, C, lda, ldb
+
+
 def mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """mean((a - b)^2) as an fp32 device scalar: two launches, no copies, fixed summation order (csrc/loss_ops.hip)"""
     lib = _lib.load()
     assert a.shape == b.shape and a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float32) and a.is_cuda
-    a, rows, C, lda = _mse_view(a)
-    b, rows_b, C_b, ldb = _mse_view(b)
-    if (rows_b, C_b) != (rows, C):                         # different row shapes for the same elements: flatten both
-        a, rows, C, lda = _mse_view(a.contiguous().reshape(-1))
-        b, _, _, ldb = _mse_view(b.contiguous().reshape(-1))
-    assert C % 8 == 0, "aptp_mse needs a multiple of 8 elements per row"
+    _, a, b, rows, C, lda, ldb = _mse_operands(a, b)
     nblk = lib.aptp_mse_nblocks(rows, C)
     partial = torch.empty(nblk, dtype=torch.float32, device=a.device)
     out = torch.empty((), dtype=torch.float32, device=a.device)
@@ -874,21 +889,21 @@ def mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def mse_bwd(a: torch.Tensor, b: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
-    """d mean((a - b)^2) / da * g = (a - b) * 2 g / n, in a's dtype and shape (contiguous)"""
+    """d mean((a - b)^2) / da * g = (a - b) * 2 g / n, in a's dtype, shape AND memory order (the gradient of the NCHW face of
+    a channels-last activation is channels-last again, so the next backward kernel takes it without a copy)"""
     lib = _lib.load()
-    shape = a.shape
-    a, rows, C, lda = _mse_view(a)
-    b, rows_b, C_b, ldb = _mse_view(b)
-    if (rows_b, C_b) != (rows, C):
-        a, rows, C, lda = _mse_view(a.contiguous().reshape(-1))
-        b, _, _, ldb = _mse_view(b.contiguous().reshape(-1))
+    order, a2, b2, rows, C, lda, ldb = _mse_operands(a, b)
     g = g.detach().to(torch.float32).reshape(1)
-    da = torch.empty(shape, dtype=a.dtype, device=a.device)
+    pshape = [a.shape[d] for d in order]
+    da = torch.empty(pshape, dtype=a.dtype, device=a.device)
     p = MseParams()
-    p.a, p.lda, p.b, p.ldb, p.rows, p.C, p.f32 = a.data_ptr(), lda, b.data_ptr(), ldb, rows, C, int(a.dtype == torch.float32)
+    p.a, p.lda, p.b, p.ldb, p.rows, p.C, p.f32 = a2.data_ptr(), lda, b2.data_ptr(), ldb, rows, C, int(a.dtype == torch.float32)
     p.g, p.da, p.ldda, p.backward = g.data_ptr(), da.data_ptr(), C, 1
     _lib.check(lib.aptp_mse(ctypes.byref(p), _stream()), "aptp_mse(bwd)")
-    return da
+    inv = [0] * len(order)
+    for i, d in enumerate(order):
+        inv[d] = i
+    return da.permute(inv)
 
 
 def fold_rows(partials: torch.Tensor, n_rows: int, C: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

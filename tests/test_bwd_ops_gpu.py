@@ -287,7 +287,7 @@ def test_fold_rows_and_pack_dgrad_from_packed(ops, cuda):
         assert got.w.shape == want.w.shape and torch.equal(got.w, want.w), (N, C, k)
 
 
-@pytest.mark.parametrize("case", ["bf16_nhwc", "bf16_slice", "f32_nchw", "bf16_big", "odd_rows"])
+@pytest.mark.parametrize("case", ["bf16_nhwc", "bf16_slice", "f32_nchw", "bf16_big", "odd_rows", "nchw_face"])
 def test_mse_matches_torch_fp64(cuda, case):
     """ops.mse / autograd.MseFn (csrc/loss_ops.hip) vs F.mse_loss in fp64: value to fp32 summation accuracy, gradient to the
     rounding of its own dtype; row-strided operands (a channel slice of a skip-concat buffer) are read in place."""
@@ -307,10 +307,16 @@ def test_mse_matches_torch_fp64(cuda, case):
     elif case == "bf16_big":
         a = (3 * torch.randn(4, 64, 64, 320, generator=g)).to(cuda, torch.bfloat16)
         b = (3 * torch.randn(4, 64, 64, 320, generator=g)).to(cuda, torch.bfloat16)
+    elif case == "nchw_face":
+        # what the block hooks hand over: the NCHW face of a channels-last activation; the teacher's is a channel slice of a
+        # skip-concat buffer.  Read in place, and the gradient comes back channels-last
+        a = torch.randn(2, 8, 8, 640, generator=g).to(cuda, torch.bfloat16).permute(0, 3, 1, 2)
+        b = torch.randn(2, 8, 8, 960, generator=g).to(cuda, torch.bfloat16)[..., :640].permute(0, 3, 1, 2)
+        assert not a.is_contiguous() and not b.is_contiguous()
     else:
         a = torch.randn(3, 5, 7, 24, generator=g).to(cuda, torch.bfloat16)
         b = torch.randn(3, 5, 7, 24, generator=g).to(cuda, torch.bfloat16)
-    a1 = a.clone().requires_grad_()
+    a1 = a.detach().requires_grad_()
     a2 = a.clone().double().requires_grad_()
     got = AG.mse(a1, b)
     ref = F.mse_loss(a2, b.double())
@@ -319,6 +325,8 @@ def test_mse_matches_torch_fp64(cuda, case):
     (got * 3.0).backward()
     (ref * 3.0).backward()
     assert a1.grad.dtype == a.dtype and a1.grad.shape == a.shape
+    if case == "nchw_face":
+        assert a1.grad.permute(0, 2, 3, 1).is_contiguous()
     assert rel_l2(a1.grad, a2.grad) <= (1e-6 if a.dtype == torch.float32 else 4e-3)
     assert torch.equal(AG.mse(a1.detach(), b), got.detach())          # fixed summation order: same bits every call
 

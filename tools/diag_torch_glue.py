@@ -1,0 +1,64 @@
+"""Which torch elementwise / copy kernels with >= 1 M elements does one eager pruning step (student forward + backward) issue,
+and from where?  (They are what is left of 'torch glue' inside the captured student graphs.)  usage: python tools/diag_torch_glue.py"""
+import collections
+import os
+import sys
+import traceback
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from diffusion_pruning_amd.hypernet import HyperStructure
+from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+from diffusion_pruning_amd.train_step import PrunerStep, synthetic_batch
+from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+
+dev = torch.device("cuda:0")
+unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
+unet.freeze()
+st = unet.get_structure()
+torch.manual_seed(0)
+hn = HyperStructure(structure=st, input_dim=768, wn_flag=False, linear_bias=True).to(dev)
+qz = StructureVectorQuantizer(n_e=8, structure=st, temperature=0.4, base=3, resource_aware_normalization=False,
+                              optimal_transport=True).to(dev)
+hn.train(); qz.train()
+step = PrunerStep(unet, hn, qz)
+step.count_macs(64)
+b = synthetic_batch(4, 64, dev)
+
+
+class Big(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.c = collections.Counter()
+        self.bytes = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        t = out if isinstance(out, torch.Tensor) else None
+        name = str(func)
+        if t is not None and t.is_cuda and t.numel() >= (1 << 20) and not any(s in name for s in ("view", "permute", "slice", "detach",
+                                                                                              "t.default", "alias", "expand", "select", "unsqueeze", "squeeze", "as_strided", "reshape", "transpose", "narrow", "split", "unbind")):
+            fr = [f for f in traceback.extract_stack() if "diffusion_pruning_amd" in f.filename]
+            where = (fr[-1].filename.split("/")[-1], fr[-1].lineno) if fr else ("autograd engine", 0)
+            self.c[(name, where)] += 1
+            self.bytes[(name, where)] += t.numel() * t.element_size()
+        return out
+
+
+def run():
+    out = step.step(b["noisy_latents"], b["timesteps"], b["encoder_hidden_states"], b["mpnet_embeddings"], b["target"])
+    out["loss"].backward()
+
+
+run()
+torch.cuda.synchronize()
+with Big() as big:
+    run()
+torch.cuda.synchronize()
+tot = 0
+for k, n in sorted(big.c.items(), key=lambda kv: -big.bytes[kv[0]])[:40]:
+    print(f"{n:4d} x {big.bytes[k] / n / 1e6:7.1f} MB  {k[0]:36s} {k[1]}")
+    tot += big.bytes[k]
+print("total output bytes of big torch ops per step: %.1f MB" % (tot / 1e6))

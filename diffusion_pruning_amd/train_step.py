@@ -370,14 +370,36 @@ class GraphedPrunerStep(PrunerStep):
         B = st["noisy_latents"].shape[0]
         ones = torch.ones((B, self.quantizer.vq_embed_dim), device=dev)
         full = self.hyper_net.transform_structure_vector(ones)
-        # ONE static buffer holds the student's architecture code; the 84 gate tensors the U-Net reads are autograd LEAVES
-        # whose storage is a column range of it (no autograd edge outside the captured region: a view node recorded on the
-        # legacy default stream would make the captured backward hop streams), so a step installs a new code with one copy,
-        # and the captured backward ends by concatenating the 84 gate gradients into one [B, 1634] tensor
-        ga = ones.clone()
-        proto = self.hyper_net.transform_structure_vector(ga)
-        gw = [t.detach().requires_grad_(True) for t in proto["width"]]
-        gd = [t.detach().requires_grad_(True) for t in proto["depth"]]
+        # ONE static buffer holds the student's architecture code, SEGMENT-MAJOR: gate j's [B, w_j] block is contiguous, so
+        # the 84 gate tensors the U-Net reads are contiguous autograd LEAVES aliasing it (a column slice of a [B, 1634]
+        # matrix would make every kernel wrapper take a strided -> contiguous copy of its gate: 231 five-microsecond copies
+        # per replay).  No autograd edge outside the captured region (a view node recorded on the legacy default stream would
+        # make the captured backward hop streams).  A step installs a new code with one gather (`install_code`), and the
+        # captured backward ends by concatenating the 84 gate gradients and gathering them back into [B, 1634] order.
+        widths = list(self.hyper_net.width_list)
+        n_depth = sum(self.hyper_net.depth_list)
+        E = sum(widths) + n_depth
+        assert E == self.quantizer.vq_embed_dim
+        col = torch.arange(E)
+        perm, s0 = [], 0
+        for w in widths + [1] * n_depth:                          # position in the flat buffer -> index into arch.reshape(-1)
+            perm.append((torch.arange(B)[:, None] * E + col[s0:s0 + w][None, :]).reshape(-1))
+            s0 += w
+        perm = torch.cat(perm)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        perm, inv = perm.to(dev), inv.to(dev)
+        ga = torch.ones(B * E, device=dev)
+        gw, gd, s0 = [], [], 0
+        for w in widths:
+            gw.append(ga[s0:s0 + B * w].view(B, w).detach().requires_grad_(True))
+            s0 += B * w
+        for _ in range(n_depth):
+            gd.append(ga[s0:s0 + B].detach().requires_grad_(True))
+            s0 += B
+
+        def install_code(arch):
+            torch.index_select(arch.detach().reshape(-1), 0, perm, out=ga)
         from .macs import VectorizedMacs
         vmacs = VectorizedMacs(self.unet, device=dev)
 
@@ -395,7 +417,8 @@ class GraphedPrunerStep(PrunerStep):
             loss, dist, blk = self._unet_losses(pred, acts, full_pred, teacher_acts, st["snr_w"], st["target"])
             total = loss + cfg.distillation_weight * dist + cfg.block_weight * blk
             grads = torch.autograd.grad(total, gw + gd, allow_unused=True)
-            grad = torch.cat([(torch.zeros_like(t) if g is None else g).reshape(B, -1) for g, t in zip(grads, gw + gd)], dim=1)
+            flat = torch.cat([(torch.zeros_like(t) if g is None else g).reshape(-1) for g, t in zip(grads, gw + gd)])
+            grad = flat[inv].view(B, E)                        # back to the architecture vector's [B, 1634] order
             return loss.detach(), dist.detach(), blk.detach(), grad
 
         # warm-up on a side stream (allocator / plan caches), then capture: the module state at capture time decides what
@@ -426,7 +449,8 @@ class GraphedPrunerStep(PrunerStep):
         g_student_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_student_bwd, pool=g_student.pool()):
             loss, dist, blk, grad = student_bwd(pred, acts, full_pred, teacher_acts)
-        self._cap = dict(st=st, ga=ga, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
+        # (everything a captured kernel reads must outlive the graphs: `inv` is an operand of the gather that ends g_student_bwd)
+        self._cap = dict(st=st, ga=ga, install_code=install_code, perm=perm, inv=inv, full=full, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
                          loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs)
         return self
 
@@ -458,7 +482,7 @@ class GraphedPrunerStep(PrunerStep):
         std_loss = -torch.std(ratios)
 
         with torch.no_grad():
-            cap["ga"].copy_(arch_used)
+            cap["install_code"](arch_used)
         cap["g_student"].replay()                                     # forward: needs the code only
         torch.cuda.current_stream().wait_stream(cap["side"])          # teacher outputs ready
         cap["g_student_bwd"].replay()                                 # losses against the teacher + backward to the code

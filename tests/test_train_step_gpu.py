@@ -211,7 +211,7 @@ def test_teacher_graph_next_to_student_forward_is_race_free(cuda):
     step.capture(batch)
     cap = step._cap
     g = torch.Generator().manual_seed(9)
-    cap["ga"].copy_((torch.rand(cap["ga"].shape, generator=g) * 0.6 + 0.4).to(cuda))
+    cap["install_code"]((torch.rand(batch["noisy_latents"].shape[0], step.quantizer.vq_embed_dim, generator=g) * 0.6 + 0.4).to(cuda))
 
     def replay(overlap: bool):
         step._stage_batch_and_launch_teacher(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"],

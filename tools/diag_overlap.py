@@ -50,7 +50,7 @@ step._unet_losses = losses_both_ways
 step.capture(batch)
 cap = step._cap
 g = torch.Generator().manual_seed(9)
-cap["ga"].copy_((torch.rand(cap["ga"].shape, generator=g) * 0.6 + 0.4).to(cuda))
+cap["install_code"]((torch.rand(batch["noisy_latents"].shape[0], step.quantizer.vq_embed_dim, generator=g) * 0.6 + 0.4).to(cuda))
 
 
 def replay(overlap):

@@ -22,6 +22,22 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rc(t: torch.Tensor) -> torch.Tensor:
+    """`t` itself when its rows of channels lie at one constant stride (a contiguous tensor, or a channel slice of a wider
+    buffer such as one third of a fused dq|dk|dv gradient or one half of a skip-concat gradient) -- the GEMM, weight-gradient
+    and column-sum kernels take a leading dimension -- else a contiguous copy."""
+    if t.is_contiguous():
+        return t
+    if t.dim() >= 2 and t.stride(-1) == 1:
+        ld = t.stride(-2)
+        ok = ld >= t.shape[-1] and ld % 8 == 0 and t.data_ptr() % 16 == 0
+        for d in range(t.dim() - 2, 0, -1):
+            ok = ok and (t.shape[d - 1] == 1 or t.stride(d - 1) == t.stride(d) * t.shape[d])
+        if ok and all(n > 1 for n in t.shape[1:-1]):       # size-1 middle dimensions have arbitrary strides: keep it simple
+            return t
+    return t.contiguous()
+
+
 class ConvFn(Function):
     """y = conv(x, w) + bias (+ rowbias[b]) (+ residual) on [B,H,W,C] (or tokens [B,L,C]); backward = dgrad through the same
     kernel; the residual (the ``+ x`` of a resnet / transformer sub-block, blocks.py:369,791,815,823) is added in the GEMM's
@@ -46,7 +62,7 @@ class ConvFn(Function):
         if not ctx.needs_input_grad[0]:
             return (None,) * 8 + (dres,)
         pwb = get_bwd()
-        dy = _c(dy.to(torch.bfloat16))
+        dy = _rc(dy.to(torch.bfloat16))
         if dres is not None:
             dres = dy
         if tokens:
@@ -244,10 +260,14 @@ class ConvWFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, pw: PackedWeight, get_bwd, stride: int, pad: int, ups: int, out_f32: bool,
-                live_out: Optional[torch.Tensor], live_in: Optional[torch.Tensor], rowbias: Optional[torch.Tensor] = None):
+                live_out: Optional[torch.Tensor], live_in: Optional[torch.Tensor], rowbias: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None):
         tokens = x.dim() == 3
         xin = x.unsqueeze(2) if tokens else x
-        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32, rowbias=rowbias)
+        res = None
+        if residual is not None:
+            res = residual.unsqueeze(2) if tokens else residual
+        y = ops.conv_gemm(xin, pw, stride=stride, pad=pad, ups=ups, out_f32=out_f32, rowbias=rowbias, residual=res)
         ctx.rowbias_shape = None if rowbias is None else tuple(rowbias.shape)
         ctx.save_for_backward(x, weight, bias if bias is not None else weight.new_zeros(0), live_out if live_out is not None else
                               torch.zeros(0, dtype=torch.long, device=x.device),
@@ -259,7 +279,7 @@ class ConvWFn(Function):
     def backward(ctx, dy):
         x, weight, bias, live_out, live_in = ctx.saved_tensors
         pw, get_bwd, stride, pad, ups, tokens, has_bias, has_lo, has_li = ctx.meta
-        dy = _c(dy.to(torch.bfloat16))
+        dy = _rc(dy.to(torch.bfloat16))
         dx = dW = db = None
         k = pw.KH
         if ctx.needs_input_grad[0]:
@@ -291,12 +311,15 @@ class ConvWFn(Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = _scatter_rows(bias, ops.colsum(dy)[:n_live], live_out if has_lo else None)
         drb = _rowbias_grad(dy, ctx.rowbias_shape) if (ctx.rowbias_shape is not None and ctx.needs_input_grad[11]) else None
-        return dx, dW, db, None, None, None, None, None, None, None, None, drb
+        return dx, dW, db, None, None, None, None, None, None, None, None, drb, (dy if ctx.needs_input_grad[12] else None)
 
 
-def conv_w(x, wparam, bparam, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None, rowbias=None):
+def conv_w(x, wparam, bparam, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None, rowbias=None,
+           residual=None):
     pad = pw.KH // 2 if pad is None else pad
-    return ConvWFn.apply(x, wparam, bparam, pw, get_bwd, stride, pad, ups, out_f32, live_out, live_in, rowbias)
+    if residual is not None and not (residual.dtype == torch.bfloat16 and not out_f32):
+        return ConvWFn.apply(x, wparam, bparam, pw, get_bwd, stride, pad, ups, out_f32, live_out, live_in, rowbias) + residual
+    return ConvWFn.apply(x, wparam, bparam, pw, get_bwd, stride, pad, ups, out_f32, live_out, live_in, rowbias, residual)
 
 
 def _rowbias_grad(dy: torch.Tensor, shape) -> torch.Tensor:
@@ -329,7 +352,7 @@ class ConvPFn(Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         pw, get_bwd, stride, pad, ups, tokens, pshape, has_bias = ctx.meta
-        dy = _c(dy.to(torch.bfloat16))
+        dy = _rc(dy.to(torch.bfloat16))
         dx = dP = db = None
         k = pw.KH
         if ctx.needs_input_grad[0]:
@@ -357,6 +380,8 @@ class ConvPFn(Function):
 
 def conv_p(x, P, Pb, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, residual=None, rowbias=None):
     pad = pw.KH // 2 if pad is None else pad
+    if residual is not None and not (residual.dtype == torch.bfloat16 and not out_f32):
+        return ConvPFn.apply(x, P, Pb, pw, get_bwd, stride, pad, ups, out_f32, None, rowbias) + residual
     return ConvPFn.apply(x, P, Pb, pw, get_bwd, stride, pad, ups, out_f32, residual, rowbias)
 
 

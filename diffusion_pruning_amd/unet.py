@@ -138,14 +138,14 @@ def _rowbias_of(tproj: torch.Tensor, n: int) -> torch.Tensor:
     return torch.nn.functional.pad(tproj, (0, n - tproj.shape[1]))
 
 
-def _cw(mod, x, weight, bias, pw, get_bwd, **kw):
+def _cw(mod, x, weight, bias, pw, get_bwd, residual=None, **kw):
     """weight-gradient convolution of the fine-tuning path: diffusers-layout masters (AG.conv_w) or, under a PackedTrainer
-    (packed_train.py), the packed masters"""
+    (packed_train.py), the packed masters; `residual` (the ``+ x`` of a sub-block) is added in the GEMM epilogue"""
     from . import autograd as AG
     pk = mod.__dict__.get("_pk")
     if pk is not None:
-        return pk.conv(x, weight, bias, pw, get_bwd, **kw)
-    return AG.conv_w(x, weight, bias, pw, get_bwd, **kw)
+        return pk.conv(x, weight, bias, pw, get_bwd, residual=residual, **kw)
+    return AG.conv_w(x, weight, bias, pw, get_bwd, residual=residual, **kw)
 
 
 def _gnw(mod, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live):
@@ -412,7 +412,7 @@ class ResnetBlock2DWidthGated(nn.Module):
             sc = _cw(self, x, self.conv_shortcut.weight, self.conv_shortcut.bias, pl["wsc"],
                            self._sel_bwd_pack(pl, "wsc", self.conv_shortcut.weight, dev), pad=0)
         out = _cw(self, a2, self.conv2.weight, self.conv2.bias, pl["w2"],
-                        self._sel_bwd_pack(pl, "w2", self.conv2.weight, dev, None, live), live_in=live) + sc
+                        self._sel_bwd_pack(pl, "w2", self.conv2.weight, dev, None, live), live_in=live, residual=sc)
         return _nchw(out)
 
     def forward(self, input_tensor: torch.Tensor, temb, scale: float = 1.0):
@@ -794,10 +794,10 @@ class Transformer2DModelWidthGated(nn.Module):
                                           cin_pad_to=cin_pad_to, device=dev)
             return pl[key]
 
-        def lin(xx, name, mod, lo=None, li=None):
+        def lin(xx, name, mod, lo=None, li=None, residual=None):
             b = mod.bias
             return _cw(self, xx, mod.weight, b, pack(name, mod.weight, b, lo, li), bwd(name, mod.weight, lo, li), pad=0,
-                             live_out=lo, live_in=li)
+                             live_out=lo, live_in=li, residual=residual)
 
         def live_of(gate, width):
             # (cached in the plan: the index tensor is uploaded once, never while a stream is capturing)
@@ -823,7 +823,7 @@ class Transformer2DModelWidthGated(nn.Module):
         h1 = a1.heads if h1 is None else h1
         qkv = torch.cat([lin(n, "a1q", a1.to_q, l1), lin(n, "a1k", a1.to_k, l1), lin(n, "a1v", a1.to_v, l1)], dim=-1)
         o = AG.SelfAttnFn.apply(qkv, h1)
-        h = lin(o, "a1o", a1.to_out[0], None, l1) + h
+        h = lin(o, "a1o", a1.to_out[0], None, l1, residual=h)        # "+ h" in the GEMM epilogue (its gradient is dy itself)
         # cross attention
         n = _lnw(self, h, tb.norm2.weight, tb.norm2.bias, pl["ln2_g"], pl["ln2_b"], 1e-5)
         a2 = tb.attn2
@@ -834,7 +834,7 @@ class Transformer2DModelWidthGated(nn.Module):
         q = lin(n, "a2q", a2.to_q, l2)
         kv = torch.cat([lin(ehs, "a2k", a2.to_k, l2), lin(ehs, "a2v", a2.to_v, l2)], dim=-1)
         o = AG.CrossAttnFn.apply(q, kv, h2)
-        h = lin(o, "a2o", a2.to_out[0], None, l2) + h
+        h = lin(o, "a2o", a2.to_out[0], None, l2, residual=h)
         # feed-forward
         n = _lnw(self, h, tb.norm3.weight, tb.norm3.bias, pl["ln3_g"], pl["ln3_b"], 1e-5)
         geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
@@ -842,8 +842,8 @@ class Transformer2DModelWidthGated(nn.Module):
         lo2 = None if lf is None else torch.cat([lf, lf + geglu.dim_out])
         hg = lin(n, "ff1", geglu.proj, lo2)
         f = AG.GegluFn.apply(hg, None)
-        h = lin(f, "ff2", lin2, None, lf) + h
-        out = lin(h, "proj_out", self.proj_out) + x_tok
+        h = lin(f, "ff2", lin2, None, lf, residual=h)
+        out = lin(h, "proj_out", self.proj_out, residual=x_tok)
         return _nchw(out.reshape(B, H, W, C))
 
     # ---- forward --------------------------------------------------------------------------------------------------

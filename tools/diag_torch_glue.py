@@ -14,6 +14,11 @@ from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
 from diffusion_pruning_amd.train_step import PrunerStep, synthetic_batch
 from diffusion_pruning_amd.unet import UNet2DConditionModelGated
 
+FT = "--ft" in sys.argv          # the packed-masters fine-tune step instead of the pruning step
+THRESH = (1 << 18) if FT else (1 << 20)
+COPIES = "--copies" in sys.argv  # only copy-like ops, from 16 K elements up
+if COPIES:
+    THRESH = 1 << 14
 dev = torch.device("cuda:0")
 unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
 unet.freeze()
@@ -23,9 +28,25 @@ hn = HyperStructure(structure=st, input_dim=768, wn_flag=False, linear_bias=True
 qz = StructureVectorQuantizer(n_e=8, structure=st, temperature=0.4, base=3, resource_aware_normalization=False,
                               optimal_transport=True).to(dev)
 hn.train(); qz.train()
-step = PrunerStep(unet, hn, qz)
-step.count_macs(64)
 b = synthetic_batch(4, 64, dev)
+if FT:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_finetune import expert_mask
+    from diffusion_pruning_amd.packed_train import PackedTrainer
+    from diffusion_pruning_amd.train_step import FineTunerStep
+    from diffusion_pruning_amd.unet import UNet2DConditionModelPruned
+    student = UNet2DConditionModelPruned()
+    student.load_state_dict(unet.state_dict())
+    unet.set_structure({"width": [torch.ones(1, w, device=dev) for sub in st["width"] for w in sub],
+                        "depth": [torch.ones(1, device=dev) for sub in st["depth"] for d in sub if d == 1]})
+    student.to(dev)
+    student.prune(expert_mask(st, 3, dev))
+    ft = FineTunerStep(student, unet)
+    pk = PackedTrainer(student).attach().materialize(b["noisy_latents"], b["timesteps"], b["encoder_hidden_states"])
+    opt = torch.optim.AdamW(pk.parameters(), lr=1e-5, fused=True)
+else:
+    step = PrunerStep(unet, hn, qz)
+    step.count_macs(64)
 
 
 class Big(TorchDispatchMode):
@@ -38,16 +59,23 @@ class Big(TorchDispatchMode):
         out = func(*args, **(kwargs or {}))
         t = out if isinstance(out, torch.Tensor) else None
         name = str(func)
-        if t is not None and t.is_cuda and t.numel() >= (1 << 20) and not any(s in name for s in ("view", "permute", "slice", "detach",
+        if "empty" in name or "_foreach" in name or "fused_adam" in name:
+            return out
+        if COPIES and not any(k in name for k in ("clone", "copy", "contiguous", "cat", "pad", "stack", "index", "zeros", "fill")):
+            return out
+        if t is not None and t.is_cuda and t.numel() >= THRESH and not any(s in name for s in ("view", "permute", "slice", "detach",
                                                                                               "t.default", "alias", "expand", "select", "unsqueeze", "squeeze", "as_strided", "reshape", "transpose", "narrow", "split", "unbind")):
             fr = [f for f in traceback.extract_stack() if "diffusion_pruning_amd" in f.filename]
-            where = (fr[-1].filename.split("/")[-1], fr[-1].lineno) if fr else ("autograd engine", 0)
+            where = tuple((f.filename.split("/")[-1], f.lineno) for f in fr[-2:]) if fr else ("autograd engine", 0)
             self.c[(name, where)] += 1
             self.bytes[(name, where)] += t.numel() * t.element_size()
         return out
 
 
 def run():
+    if FT:
+        ft.train_step(opt, b)
+        return
     out = step.step(b["noisy_latents"], b["timesteps"], b["encoder_hidden_states"], b["mpnet_embeddings"], b["target"])
     out["loss"].backward()
 

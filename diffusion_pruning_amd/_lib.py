@@ -131,7 +131,7 @@ class WgradParams(Structure):
     _fields_ = [
         ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dw", c_void_p),
         ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("N", c_int32), ("KH", c_int32), ("KW", c_int32),
-        ("split_m", c_int32), ("ld_dw", c_int32),
+        ("split_m", c_int32), ("ld_dw", c_int32), ("db", c_void_p),
     ]
 
 
@@ -194,7 +194,7 @@ class UnetEpilogueParams(Structure):
 
 
 class ColsumParams(Structure):
-    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("rows", c_int32), ("C", c_int32), ("partial", c_void_p)]
+    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("rows", c_int32), ("C", c_int32), ("partial", c_void_p), ("batch", c_int32)]
 
 
 class LayerNormPgradParams(Structure):

@@ -295,8 +295,12 @@ class ConvWFn(Function):
             dx = dx.squeeze(2) if tokens else dx
         n_live = live_out.numel() if has_lo else weight.shape[0]
         c_live = live_in.numel() if has_li else weight.shape[1]
+        want_db = has_bias and ctx.needs_input_grad[2]
+        db_raw = None
         if ctx.needs_input_grad[1]:
-            g = ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups)            # [Npad, taps, Cpad] fp32
+            g = ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups, want_db=want_db)   # [Npad, taps, Cpad] fp32 (, [Npad])
+            if want_db:
+                g, db_raw = g
             g = g[:n_live, :, :c_live].permute(0, 2, 1).reshape(n_live, c_live, pw.KH, pw.KW)
             if weight.dim() == 2:
                 g = g.reshape(n_live, c_live)
@@ -308,8 +312,8 @@ class ConvWFn(Function):
                 dW = full
             else:
                 dW = g.to(weight.dtype)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = _scatter_rows(bias, ops.colsum(dy)[:n_live], live_out if has_lo else None)
+        if want_db:
+            db = _scatter_rows(bias, (db_raw if db_raw is not None else ops.colsum(dy))[:n_live], live_out if has_lo else None)
         drb = _rowbias_grad(dy, ctx.rowbias_shape) if (ctx.rowbias_shape is not None and ctx.needs_input_grad[11]) else None
         return dx, dW, db, None, None, None, None, None, None, None, None, drb, (dy if ctx.needs_input_grad[12] else None)
 
@@ -327,8 +331,8 @@ def _rowbias_grad(dy: torch.Tensor, shape) -> torch.Tensor:
     per-sample column sums of dy, fp32, fixed order (colsum + fold kernels; a torch .sum over 4096 pixels per output may
     take the multi-block path that misbehaves inside replayed graphs, see csrc/loss_ops.hip)"""
     B, N = shape
-    g = torch.stack([ops.colsum(dy[b]) for b in range(dy.shape[0])])
-    return g[:, :N].contiguous()
+    g = ops.colsum(dy, per_sample=True)
+    return g if g.shape[1] == N else g[:, :N].contiguous()
 
 
 class ConvPFn(Function):
@@ -366,13 +370,16 @@ class ConvPFn(Function):
                     B, H2, W2, C = dx.shape
                     dx = dx.view(B, H2 // 2, 2, W2 // 2, 2, C).float().sum(dim=(2, 4)).to(torch.bfloat16)
             dx = dx.squeeze(2) if tokens else dx
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             cx = x.shape[-1]
             # straight into the packed layout [N, taps, cin_pad]: the kernel (or the slab fold) writes the first Cx columns,
-            # the pad columns stay zero
+            # the pad columns stay zero; the bias gradient is a by-product of the same kernel
             dP = (torch.zeros if pshape[2] != cx else torch.empty)(pshape, dtype=torch.float32, device=dy.device)
-            ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups, out=dP)
-        if has_bias and ctx.needs_input_grad[2]:
+            r = ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups, out=dP, want_db=want_db)
+            if want_db:
+                db = r[1][:pshape[0]]
+        elif want_db:
             db = ops.colsum(dy)[:pshape[0]]
         drb = _rowbias_grad(dy, ctx.rowbias_shape) if (ctx.rowbias_shape is not None and ctx.needs_input_grad[10]) else None
         return dx, dP, db, None, None, None, None, None, None, (dy if ctx.needs_input_grad[9] else None), drb

@@ -530,17 +530,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Column sums of a [rows, C] bf16 matrix (bias gradients): partial[chunk, c] = sum over the rows of the chunk.
+// Column sums of `batch` consecutive [rows, C] bf16 matrices (bias gradients; per-sample sums for the time-embedding bias):
+// partial[chunk, b, c] = sum over the rows of chunk `chunk` of matrix b.
 // ------------------------------------------------------------------------------------------------------------
-struct ColsumK { const __bf16* x; int64_t ldx; int rows, C, CO, nchunk, TPR, RPAR; float* partial; };
+struct ColsumK { const __bf16* x; int64_t ldx; int rows, C, CO, nchunk, TPR, RPAR; float* partial; int batch; };
 
 template <int NP>
 __global__ __launch_bounds__(256) void colsum_kernel(const ColsumK p) {
   __shared__ float red[6144];
-  const int tid = threadIdx.x, chunk = blockIdx.x;
+  const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;     // b: sample (rows = rows PER sample)
   const int r0 = (int)(((int64_t)p.rows * chunk) / p.nchunk), r1 = (int)(((int64_t)p.rows * (chunk + 1)) / p.nchunk);
   const int rl = tid / p.TPR, ot = tid - rl * p.TPR;
   const bool active = rl < p.RPAR;
+  const __bf16* xb = p.x + (int64_t)b * p.rows * p.ldx;
   float acc[NP][8];
 #pragma unroll
   for (int pg = 0; pg < NP; ++pg)
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumK p) {
         const int o = ot + pg * 256;
         if (o < p.CO) {
           float f[8];
-          unpack8(*reinterpret_cast<const u32x4*>(p.x + (int64_t)r * p.ldx + o * 8), f);
+          unpack8(*reinterpret_cast<const u32x4*>(xb + (int64_t)r * p.ldx + o * 8), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[pg][e] += f[e];
         }
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumK p) {
   for (int c = tid; c < p.C; c += 256) {
     float v = 0.f;
     for (int rr = 0; rr < p.RPAR; ++rr) v += red[rr * CP + c];
-    p.partial[(int64_t)chunk * p.C + c] = v;
+    p.partial[((int64_t)chunk * p.batch + b) * p.C + c] = v;
   }
 }
 
@@ -798,7 +800,9 @@ extern "C" int aptp_colsum(const AptpColsumParams* p, aptp_stream_t stream) {
   ColsumK k;
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.rows = p->rows; k.C = p->C; k.CO = p->C / 8;
   k.nchunk = aptp_groupnorm_nchunk(p->rows); k.TPR = k.CO < 256 ? k.CO : 256; k.RPAR = 256 / k.TPR; k.partial = p->partial;
-  dim3 grid(k.nchunk);
+  k.batch = p->batch > 0 ? p->batch : 1;
+  APTP_CHECK(k.batch <= 65535, "colsum: batch");
+  dim3 grid(k.nchunk, k.batch);
   hipStream_t s = (hipStream_t)stream;
   if (k.CO <= 256) hipLaunchKernelGGL(colsum_kernel<1>, grid, dim3(256), 0, s, k);
   else if (k.CO <= 512) hipLaunchKernelGGL(colsum_kernel<2>, grid, dim3(256), 0, s, k);

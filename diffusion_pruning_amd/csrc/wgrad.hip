@@ -29,6 +29,7 @@ struct WgK {
   int B, H, W, C, N, M, HW, split, nsteps, tiles_n, tiles_c;
   int Wt, R, hw2;      // halo geometry (3x3): tile width, rows per step, Wt + 2
   int ldw;             // row length of dw's c dimension
+  float* db;           // optional [split][N]: column sums of dy over the slice (written by the workgroups of c-block 0)
 };
 
 constexpr int PITCH = 72;          // bf16 elements per LDS row (64 + 8: spreads the 4-row transposed blocks over the banks)
@@ -59,6 +60,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   const int s_begin = (int)(((int64_t)p.nsteps * slice) / p.split), s_end = (int)(((int64_t)p.nsteps * (slice + 1)) / p.split);
 
   // ---- staging registers -------------------------------------------------------------------------------------------------
+  // bias gradient: the thread's dy chunk is 8 output channels of one pixel; it stages the same chunk column every step, so it
+  // keeps their running sums (c-block 0 only: every c-block stages the same dy tiles)
+  const bool want_db = p.db != nullptr && tc == 0;
+  float dbacc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dbacc[e] = 0.f;
   u32x4 rdy, rx[XCH];
   const int dj = tid >> 3, dch = tid & 7;          // dy tile: row (pixel of the step), 16-byte chunk
   const int xrows = TAPS == 9 ? (p.R + 2) * p.hw2 : 32;
@@ -91,6 +98,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   };
   auto store_step = [&](int buf) {
     *reinterpret_cast<u32x4*>(&dys[buf][dj * PITCH + dch * 8]) = rdy;
+    if (want_db) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(&rdy), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dbacc[e] += f[e];
+    }
     if (TAPS == 9) {
 #pragma unroll
       for (int i = 0; i < XCH; ++i) {
@@ -140,6 +153,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
         }
       }
       buf ^= 1;
+    }
+  }
+
+  // ---- bias-gradient slab: fold the 32 threads that share a chunk column (fixed order), one value per output channel ---------
+  if (want_db) {
+    __syncthreads();                                             // the last step's fragment reads are done: reuse dys as fp32 scratch
+    float* red = reinterpret_cast<float*>(&dys[0][0]);           // 32 x 64 floats = 8 KiB <= sizeof(dys)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[dj * 64 + dch * 8 + e] = dbacc[e];
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.N) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) v += red[r * 64 + tid];
+      p.db[(int64_t)slice * p.N + n0 + tid] = v;
     }
   }
 
@@ -195,6 +223,7 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   k.B = p->B; k.H = p->H; k.W = p->W; k.C = p->C; k.N = p->N; k.HW = p->H * p->W; k.M = p->B * k.HW;
   k.nsteps = (k.M + 31) / 32;
   k.ldw = p->ld_dw ? p->ld_dw : p->C;
+  k.db = p->db;
   APTP_CHECK(k.ldw >= p->C && k.ldw % 4 == 0, "conv_wgrad: ld_dw");
   k.split = p->split_m > k.nsteps ? k.nsteps : p->split_m;
   APTP_CHECK(k.split == p->split_m, "conv_wgrad: split_m %d exceeds the %d K-steps", p->split_m, k.nsteps);

@@ -1077,18 +1077,21 @@ def layernorm_pgrad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5):
     return pg[:, 1].contiguous(), pg[:, 0].contiguous()
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
-    """fp32 column sums of a bf16 [..., C] tensor with contiguous last dim and uniform row stride (bias gradients)."""
+def colsum(x: torch.Tensor, per_sample: bool = False) -> torch.Tensor:
+    """fp32 column sums of a bf16 [..., C] tensor with contiguous last dim and uniform row stride (bias gradients): [C];
+    per_sample: one sum per leading index, [B, C] (the gradient of a per-sample output bias), still two launches."""
     lib = _lib.load()
     C = x.shape[-1]
+    B = x.shape[0] if per_sample else 1
     x2 = x.reshape(-1, C)
-    rows = x2.shape[0]
+    rows = x2.shape[0] // B
     nchunk = lib.aptp_groupnorm_nchunk(rows)
-    part = torch.empty(nchunk, C, dtype=torch.float32, device=x.device)
+    part = torch.empty(nchunk, B, C, dtype=torch.float32, device=x.device)
     p = ColsumParams()
-    p.x, p.ldx, p.rows, p.C, p.partial = x2.data_ptr(), (x2.stride(0) if rows > 1 else C), rows, C, part.data_ptr()
+    p.x, p.ldx, p.rows, p.C, p.partial, p.batch = x2.data_ptr(), (x2.stride(0) if x2.shape[0] > 1 else C), rows, C, part.data_ptr(), B
     _lib.check(lib.aptp_colsum(ctypes.byref(p), _stream()), "aptp_colsum")
-    return fold_rows(part, 1, C).view(C)
+    out = fold_rows(part, B, C)
+    return out if per_sample else out.view(C)
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -1133,7 +1136,7 @@ WGRAD_KERNEL = os.environ.get("APTP_WGRAD_KERNEL", "1") != "0"
 
 
 def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: Optional[int] = None,
-                  out: Optional[torch.Tensor] = None):
+                  out: Optional[torch.Tensor] = None, want_db: bool = False):
     """x [B,H,W,C], dy [B,H,W,N] (bf16, channels contiguous, uniform pixel stride) -> fp32 [N, KH*KW, C] or None when
     the geometry is not handled by aptp_conv_wgrad.  out: an fp32 [N, KH*KW, ld >= C] buffer (a packed-layout gradient) that
     receives the result in its first C columns (the rest is left alone); returned instead of a fresh tensor."""
@@ -1150,16 +1153,20 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
     p.split_m = int(split_m) if split_m else lib.aptp_conv_wgrad_suggest_split(ctypes.byref(p))
     if out is not None:
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[:2]) == (N, KH * KW) and out.shape[2] >= C
+    db = torch.empty(p.split_m, N, dtype=torch.float32, device=x.device) if want_db else None
+    if want_db:
+        p.db = db.data_ptr()
     if p.split_m == 1:
         res = out if out is not None else torch.empty(N, KH * KW, C, dtype=torch.float32, device=x.device)
         p.dw, p.ld_dw = res.data_ptr(), res.shape[2]
         _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
-        return res
+        return (res, db.view(N)) if want_db else res
     slabs = torch.empty(p.split_m, N * KH * KW, C, dtype=torch.float32, device=x.device)
     p.dw = slabs.data_ptr()
     _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
     res = fold_rows(slabs, N * KH * KW, C, out=out)
-    return res if out is not None else res.view(N, KH * KW, C)
+    res = res if out is not None else res.view(N, KH * KW, C)
+    return (res, fold_rows(db, 1, N).view(N)) if want_db else res
 
 
 def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int) -> torch.Tensor:
@@ -1182,16 +1189,18 @@ def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int = 1, pad: int = 0, ups: int = 0,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, want_db: bool = False):
     """Weight gradient of y = conv(x, w): returns fp32 [N, KH*KW, C] (the packed-weight order, unpadded), or `out` (fp32
     [N, KH*KW, ld >= C], e.g. a zero-initialised packed-layout gradient) with the result in its first C columns.
-    x [B,H,W,C] (or tokens [B,L,C] with KH=KW=1), dy [B,Ho,Wo,N] (or [B,L,N]); both bf16."""
+    x [B,H,W,C] (or tokens [B,L,C] with KH=KW=1), dy [B,Ho,Wo,N] (or [B,L,N]); both bf16.
+    want_db: also return the bias gradient (fp32 [N] column sums of dy) -- a by-product of the weight-gradient kernel, which
+    stages every dy tile anyway; a separate column-sum pass only on the fallback geometries."""
     if x.dim() == 3:
         # tokens: one image of B*L x 1 "pixels" (a linear layer has no spatial structure)
         x, dy = x.reshape(1, -1, 1, x.shape[-1]), dy.reshape(1, -1, 1, dy.shape[-1])
     C, N = x.shape[-1], dy.shape[-1]
     if WGRAD_KERNEL and stride == 1 and ups == 0 and KH == KW and pad == KH // 2 and x.shape[:3] == dy.shape[:3]:
-        g = _wgrad_direct(x, dy, KH, KW, out=out)
+        g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db)
         if g is not None:
             return g
     xt = _im2col_T(x, KH, KW, stride, pad, ups)                   # [K, M]
@@ -1212,5 +1221,5 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     res = res.view(Np, Kp)[:N, :K].reshape(N, KH * KW, C)
     if out is not None:
         out[:, :, :C] = res
-        return out
-    return res
+        res = out
+    return (res, colsum(dy)) if want_db else res

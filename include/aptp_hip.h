@@ -392,6 +392,8 @@ typedef struct {
   int32_t B, H, W, C, N, KH, KW, split_m;
   int32_t ld_dw;                   /* row length of dw's innermost (c) dimension; 0 = C.  With split_m == 1 and ld_dw = cin_pad the
                                       kernel writes straight into a packed-layout gradient (pad columns are not touched) */
+  float* db;                       /* optional fp32 [split_m, N]: per-slice column sums of dy = the bias gradient's slabs (the
+                                      workgroups of input-channel block 0 sum the dy tiles they stage anyway) */
 } AptpWgradParams;
 int aptp_conv_wgrad_supported(const AptpWgradParams* p);
 int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p);
@@ -450,8 +452,9 @@ typedef struct {
 } AptpLayerNormBwdParams;
 int aptp_layernorm_bwd(const AptpLayerNormBwdParams* p, aptp_stream_t stream);
 
-/* Column sums of a bf16 [rows, C] matrix (bias gradients): partial fp32 [aptp_groupnorm_nchunk(rows), C]. */
-typedef struct { const void* x; int64_t ldx; int32_t rows, C; float* partial; } AptpColsumParams;
+/* Column sums of `batch` (0 = 1) consecutive bf16 [rows, C] matrices (bias gradients; batch > 1: per-sample sums for the
+ * gradient of a per-sample output bias): partial fp32 [aptp_groupnorm_nchunk(rows), batch, C]. */
+typedef struct { const void* x; int64_t ldx; int32_t rows, C; float* partial; int32_t batch; } AptpColsumParams;
 int aptp_colsum(const AptpColsumParams* p, aptp_stream_t stream);
 
 /* LayerNorm affine-parameter gradient partials: fp32 [aptp_groupnorm_nchunk(rows), C, 2] = (sum dy, sum dy*xhat). */

@@ -242,6 +242,10 @@ def test_conv_wgrad_kernel(ops, cuda, case, split):
         pytest.skip("more slices than K-steps")
     got = ops._wgrad_direct(xd, dyd, k, k, split_m=split)
     assert got is not None, "geometry must be handled by the kernel"
+    # the bias gradient as a by-product (column sums of dy by the workgroups of input-channel block 0): same dW bits, db = sum dy
+    got2, db = ops._wgrad_direct(xd, dyd, k, k, split_m=split, want_db=True)
+    assert torch.equal(got2, got) and tuple(db.shape) == (N,)
+    assert rel_l2(db.cpu(), dy.sum(dim=(0, 2, 3))) <= 1e-5
     torch.cuda.synchronize()
     assert tuple(got.shape) == (N, k * k, C)
     assert rel_l2(got.float().cpu(), ref) <= 2e-3                           # fp32 accumulation of bf16 products
@@ -253,6 +257,19 @@ def test_conv_wgrad_kernel(ops, cuda, case, split):
             ops.WGRAD_KERNEL = True
         assert rel_l2(got.float().cpu(), old.float().cpu()) <= 2e-3
         assert torch.equal(got, ops._wgrad_direct(xd, dyd, k, k))            # deterministic
+
+
+def test_colsum_per_sample_and_strided(ops, cuda):
+    """ops.colsum: whole-tensor and per-sample column sums (the gradient of conv1's per-sample time-embedding bias), also on a
+    channel slice of a wider buffer"""
+    g = torch.Generator().manual_seed(8)
+    wide = torch.randn(3, 16, 16, 384, generator=g).bfloat16().to(cuda)
+    for x in (wide, wide[..., 64:384]):
+        ref = x.float().sum(dim=(1, 2))
+        got = ops.colsum(x, per_sample=True)
+        assert tuple(got.shape) == tuple(ref.shape) and rel_l2(got, ref) <= 1e-5
+        assert rel_l2(ops.colsum(x), ref.sum(0)) <= 1e-5
+        assert torch.equal(ops.colsum(x, per_sample=True), got)
 
 
 def test_conv_wgrad_reads_channel_slices_in_place(ops, cuda):

@@ -252,6 +252,8 @@ EXPORTS = [
     ("aptp_conv_wgrad", c_int, [POINTER(WgradParams), c_void_p]),
     ("aptp_fold_rows", c_int, [POINTER(FoldRowsParams), c_void_p]),
     ("aptp_pack_dgrad", c_int, [POINTER(PackDgradParams), c_void_p]),
+    ("aptp_pack_dgrad_blocks", c_int, [POINTER(PackDgradParams)]),
+    ("aptp_pack_dgrad_many", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     ("aptp_mse_nblocks", c_int, [c_int64, c_int32]),
     ("aptp_mse", c_int, [POINTER(MseParams), c_void_p]),
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),

@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) {
 
 struct PackK { const __bf16* src; __bf16* dst; int N, C, taps, src_ld, dst_ld, dst_rows; };
 
-// grid (ceil(N/64), ceil(C/64), taps); tile: src rows n0..n0+63 (64 channels c0..c0+63 each) -> dst rows c0.., columns n0..
-__global__ __launch_bounds__(256) void pack_dgrad_kernel(const PackK p) {
+// tile: src rows n0..n0+63 (64 channels c0..c0+63 each) -> dst rows c0.., columns n0..
+__device__ __forceinline__ void pack_dgrad_tile(const PackK& p, int n0, int c0, int t) {
   __shared__ __bf16 tile[64][72];
-  const int tid = threadIdx.x, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, t = blockIdx.z;
+  const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + 256 * i, r = id >> 3, ch = id & 7;
@@ -92,6 +92,30 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const PackK p) {
   }
 }
 
+// grid (ceil(dst_ld/64), ceil(dst_rows/64), taps)
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const PackK p) {
+  pack_dgrad_tile(p, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z);
+}
+
+// every data-gradient operand of a model in ONE launch: items[] (device memory) describes the weights, starts[i] is the first
+// workgroup of item i (starts[n_items] = grid size); a workgroup finds its item by bisection
+__global__ __launch_bounds__(256) void pack_dgrad_many_kernel(const AptpPackDgradParams* __restrict__ items,
+                                                              const int32_t* __restrict__ starts, int n_items) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_items;                     // invariant: starts[lo] <= b < starts[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (starts[mid] <= b) lo = mid; else hi = mid;
+  }
+  const AptpPackDgradParams it = items[lo];
+  PackK p{(const __bf16*)it.src, (__bf16*)it.dst, it.N, it.C, it.taps, it.src_ld, it.dst_ld, it.dst_rows};
+  int local = b - starts[lo];
+  const int gx = (it.dst_ld + 63) / 64, gy = (it.dst_rows + 63) / 64;
+  const int bx = local % gx; local /= gx;
+  const int by = local % gy, t = local / gy;
+  pack_dgrad_tile(p, bx * 64, by * 64, t);
+}
+
 }  // namespace
 
 #define ALIGN16(p) (((uintptr_t)(p) % 16) == 0)
@@ -105,6 +129,19 @@ extern "C" int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream)
   const int64_t blocks = (work + 31) / 32;
   APTP_CHECK(blocks < (1LL << 31), "fold_rows: grid too large");
   hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}
+
+extern "C" int aptp_pack_dgrad_blocks(const AptpPackDgradParams* p) {
+  if (!p || p->dst_ld < 1 || p->dst_rows < 1 || p->taps < 1) return 0;
+  return ((p->dst_ld + 63) / 64) * ((p->dst_rows + 63) / 64) * p->taps;
+}
+
+extern "C" int aptp_pack_dgrad_many(const AptpPackDgradParams* items_dev, const int32_t* starts_dev, int32_t n_items,
+                                    int32_t total_blocks, aptp_stream_t stream) {
+  APTP_CHECK(items_dev && starts_dev && n_items >= 1 && total_blocks >= 1, "pack_dgrad_many: bad arguments");
+  hipLaunchKernelGGL(pack_dgrad_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, starts_dev, n_items);
   APTP_LAUNCH_CHECK();
   return APTP_OK;
 }

@@ -935,6 +935,37 @@ def pack_dgrad_from_packed(pw: PackedWeight, pwb: PackedWeight) -> PackedWeight:
     return pwb
 
 
+class PackDgradBatch:
+    """pack_dgrad_from_packed for a fixed list of (forward operand, data-gradient operand) pairs as ONE launch: the
+    descriptors live in device memory (built once; the operands' storage must not move afterwards)."""
+
+    def __init__(self, pairs):
+        lib = _lib.load()
+        pairs = list(pairs)
+        assert pairs
+        dev = pairs[0][0].w.device
+        items = (PackDgradParams * len(pairs))()
+        starts = [0]
+        for i, (pw, pwb) in enumerate(pairs):
+            assert pwb.KH == pw.KH and pwb.N >= pw.Cin and pwb.cin_pad >= pw.N and pw.Cin2 == 0
+            assert pw.cin_pad % 8 == 0 and pwb.cin_pad % 8 == 0 and pw.w.data_ptr() % 16 == 0 and pwb.w.data_ptr() % 16 == 0
+            p = items[i]
+            p.src, p.dst, p.N, p.C, p.taps = pw.w.data_ptr(), pwb.w.data_ptr(), pw.N, pw.Cin, pw.KH * pw.KW
+            p.src_ld, p.dst_ld, p.dst_rows = pw.cin_pad, pwb.cin_pad, pwb.N
+            starts.append(starts[-1] + lib.aptp_pack_dgrad_blocks(ctypes.byref(p)))
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.items = raw.to(dev)
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(dev)
+        self.n, self.total = len(pairs), starts[-1]
+        self.keep = pairs
+        self.key = tuple((pw.w.data_ptr(), pwb.w.data_ptr()) for pw, pwb in pairs)
+
+    def run(self):
+        lib = _lib.load()
+        _lib.check(lib.aptp_pack_dgrad_many(self.items.data_ptr(), self.starts.data_ptr(), self.n, self.total, _stream()),
+                   "aptp_pack_dgrad_many")
+
+
 def gate_bwd(dy: torch.Tensor, y0: torch.Tensor, gate: torch.Tensor, want_dgate: bool = True):
     """dx = dy * gate (expanded over channel groups, batch tiled), dgate [Bg, G] = sum dy*y0 (fp32).
     want_dgate=False: the forward gate multiply (dy := y0) -- the partials are not folded, dgate is None."""

@@ -190,11 +190,24 @@ class PackedTrainer:
 
     @torch.no_grad()
     def refresh_(self):
-        """shadows <- masters: one multi-tensor cast for the forward operands, one strided copy per data-gradient operand"""
+        """shadows <- masters: one multi-tensor cast for the forward operands, ONE launch for all data-gradient operands
+        (ops.PackDgradBatch: a table of the weights in device memory, rebuilt when an operand appears or moves)"""
         es = list(self.gemms.values())
         torch._foreach_copy_([e.pw.w for e in es], [e.P.detach() for e in es])
-        for e in es:
-            e.refresh_bwd_()
+        pairs = [(e.pw, e.pwb) for e in es if e.pwb is not None]
+        if not pairs:
+            return
+        key = tuple((pw.w.data_ptr(), pwb.w.data_ptr()) for pw, pwb in pairs)
+        batch = self.__dict__.get("_dgrad_batch")
+        if batch is None or batch.key != key:
+            if torch.cuda.is_current_stream_capturing():
+                # (the table is uploaded with a host->device copy: never while capturing; GraphedFineTunerStep's warm-up
+                # iterations run first, so this only happens when a new operand shows up mid-capture)
+                for e in es:
+                    e.refresh_bwd_()
+                return
+            batch = self._dgrad_batch = ops.PackDgradBatch(pairs)
+        batch.run()
 
     @torch.no_grad()
     def export_(self):

@@ -425,6 +425,12 @@ int aptp_mse(const AptpMseParams* p, aptp_stream_t stream);
  * (ops.pack_weight_dgrad of the same weights, without going through the diffusers layout.) */
 typedef struct { const void* src; void* dst; int32_t N, C, taps, src_ld, dst_ld, dst_rows; } AptpPackDgradParams;
 int aptp_pack_dgrad(const AptpPackDgradParams* p, aptp_stream_t stream);
+/* The same for many weights in ONE launch (the operand refresh after an optimizer step): items_dev = n_items descriptors in
+ * DEVICE memory (each validated by the caller as aptp_pack_dgrad would), starts_dev = int32 [n_items + 1] prefix sums of
+ * aptp_pack_dgrad_blocks(item) (device memory), total_blocks = starts[n_items]. */
+int aptp_pack_dgrad_blocks(const AptpPackDgradParams* p);
+int aptp_pack_dgrad_many(const AptpPackDgradParams* items_dev, const int32_t* starts_dev, int32_t n_items, int32_t total_blocks,
+                         aptp_stream_t stream);
 
 /* GroupNorm(+SiLU) data gradient.  fwd_stats = the [B, nchunk, groups, 2] (sum, sumsq) partials the forward wrote into its
  * workspace (keep that buffer alive); workspace: fp32 [B, nchunk, groups, 2]. */

@@ -302,6 +302,18 @@ def test_fold_rows_and_pack_dgrad_from_packed(ops, cuda):
         ops.pack_dgrad_from_packed(pw, got)
         torch.cuda.synchronize()
         assert got.w.shape == want.w.shape and torch.equal(got.w, want.w), (N, C, k)
+    # all four weights in ONE launch (ops.PackDgradBatch: descriptor table in device memory, workgroups bisect for their item)
+    pairs, wants = [], []
+    for (N, C, k) in [(72, 200, 3), (320, 136, 1), (8, 64, 3), (1280, 640, 1)]:
+        pw = ops.pack_weight(torch.randn(N, C, k, k, generator=g), None, device=cuda)
+        wants.append(ops.pack_weight_dgrad(pw.w[:, :, :pw.Cin].float().reshape(pw.N, k, k, pw.Cin).permute(0, 3, 1, 2), device=cuda))
+        dst = ops.pack_weight_dgrad(torch.zeros(pw.N, pw.Cin, k, k), device=cuda)
+        dst.w.fill_(7.0)
+        pairs.append((pw, dst))
+    ops.PackDgradBatch(pairs).run()
+    torch.cuda.synchronize()
+    for (pw, dst), want in zip(pairs, wants):
+        assert torch.equal(dst.w, want.w)
 
 
 @pytest.mark.parametrize("case", ["bf16_nhwc", "bf16_slice", "f32_nchw", "bf16_big", "odd_rows", "nchw_face"])

@@ -131,12 +131,13 @@ class WgradParams(Structure):
     _fields_ = [
         ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dw", c_void_p),
         ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("N", c_int32), ("KH", c_int32), ("KW", c_int32),
-        ("split_m", c_int32), ("ld_dw", c_int32), ("db", c_void_p),
+        ("split_m", c_int32), ("ld_dw", c_int32), ("db", c_void_p), ("slab_stride", c_int64), ("db_stride", c_int64),
     ]
 
 
 class FoldRowsParams(Structure):
-    _fields_ = [("partials", c_void_p), ("out", c_void_p), ("R", c_int32), ("n_rows", c_int32), ("C", c_int32), ("ld_out", c_int32)]
+    _fields_ = [("partials", c_void_p), ("out", c_void_p), ("R", c_int32), ("n_rows", c_int32), ("C", c_int32), ("ld_out", c_int32),
+                ("tail_out", c_void_p), ("tail_rows", c_int32)]
 
 
 class PackDgradParams(Structure):

@@ -10,7 +10,7 @@
 
 namespace {
 
-struct FoldK { const float* in; float* out; int R, n_rows, C, ld_out; };
+struct FoldK { const float* in; float* out; int R, n_rows, C, ld_out; float* tail_out; int rows1; };
 
 // block = 32 column quads x 8 row slices: slice s sums rows s, s+8, ... (independent 16-byte loads in flight), the slices are
 // folded 0..7 through LDS: the order is fixed, the result does not depend on scheduling
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) {
 #pragma unroll
       for (int q = 1; q < 8; ++q) { const float4 b = red[q][cq]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
       const int64_t row = e / p.C, c = e - row * p.C;
-      float* o = p.out + row * p.ld_out + c;
+      float* o = row < p.rows1 ? p.out + row * p.ld_out + c : p.tail_out + (row - p.rows1) * p.C + c;
       o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
     }
   } else {
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) t += reinterpret_cast<float*>(red)[q * 32 + cq];
       const int64_t row = e / p.C;
-      p.out[row * p.ld_out + (e - row * p.C)] = t;
+      if (row < p.rows1) p.out[row * p.ld_out + (e - row * p.C)] = t;
+      else p.tail_out[(row - p.rows1) * p.C + (e - row * p.C)] = t;
     }
   }
 }
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(256) void pack_dgrad_many_kernel(const AptpPackDgra
 extern "C" int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream) {
   APTP_CHECK(p && p->partials && p->out && p->R >= 1 && p->n_rows >= 1 && p->C >= 1 && p->ld_out >= p->C, "fold_rows: bad arguments");
   APTP_CHECK((p->C & 3) != 0 || (ALIGN16(p->partials) && (((int64_t)p->n_rows * p->C) & 3) == 0), "fold_rows: alignment");
-  FoldK k{p->partials, p->out, p->R, p->n_rows, p->C, p->ld_out};
+  APTP_CHECK(p->tail_rows >= 0 && p->tail_rows < p->n_rows && (p->tail_rows == 0 || p->tail_out), "fold_rows: tail");
+  FoldK k{p->partials, p->out, p->R, p->n_rows, p->C, p->ld_out, p->tail_out, p->n_rows - p->tail_rows};
   const int64_t total = (int64_t)p->n_rows * p->C;
   const int64_t work = (p->C & 3) == 0 ? total / 4 : total;          // column quads (or single columns), 32 per block
   const int64_t blocks = (work + 31) / 32;

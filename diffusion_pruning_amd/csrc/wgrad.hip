@@ -30,6 +30,7 @@ struct WgK {
   int Wt, R, hw2;      // halo geometry (3x3): tile width, rows per step, Wt + 2
   int ldw;             // row length of dw's c dimension
   float* db;           // optional [split][N]: column sums of dy over the slice (written by the workgroups of c-block 0)
+  int64_t slab_stride, db_stride;
 };
 
 constexpr int PITCH = 72;          // bf16 elements per LDS row (64 + 8: spreads the 4-row transposed blocks over the banks)
@@ -167,12 +168,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
       float v = 0.f;
 #pragma unroll
       for (int r = 0; r < 32; ++r) v += red[r * 64 + tid];
-      p.db[(int64_t)slice * p.N + n0 + tid] = v;
+      p.db[(int64_t)slice * p.db_stride + n0 + tid] = v;
     }
   }
 
   // ---- store: lane owns c = cbase + 4*(lane/16) .. +3 of n = nbase + lane%16 -------------------------------------------------
-  float* out = p.dw + (int64_t)slice * p.N * TAPS * p.ldw;
+  float* out = p.dw + (int64_t)slice * p.slab_stride;
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf) {
     const int n = n0 + wn * 32 + nf * 16 + (lane & 15);
@@ -224,6 +225,9 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   k.nsteps = (k.M + 31) / 32;
   k.ldw = p->ld_dw ? p->ld_dw : p->C;
   k.db = p->db;
+  k.slab_stride = p->slab_stride ? p->slab_stride : (int64_t)p->N * p->KH * p->KW * k.ldw;
+  k.db_stride = p->db_stride ? p->db_stride : p->N;
+  APTP_CHECK(k.slab_stride >= (int64_t)p->N * p->KH * p->KW * k.ldw && k.slab_stride % 4 == 0 && k.db_stride >= p->N, "conv_wgrad: slab strides");
   APTP_CHECK(k.ldw >= p->C && k.ldw % 4 == 0, "conv_wgrad: ld_dw");
   k.split = p->split_m > k.nsteps ? k.nsteps : p->split_m;
   APTP_CHECK(k.split == p->split_m, "conv_wgrad: split_m %d exceeds the %d K-steps", p->split_m, k.nsteps);

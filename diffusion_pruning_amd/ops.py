@@ -906,18 +906,26 @@ def mse_bwd(a: torch.Tensor, b: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     return da.permute(inv)
 
 
-def fold_rows(partials: torch.Tensor, n_rows: int, C: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[row, c] = sum_r partials[r, row, c] (fp32, fixed order); partials is [R, n_rows, C] contiguous; `out` may be a
-    [n_rows, ld >= C] buffer whose extra columns are left alone (the padded packed layout of a weight gradient)."""
+def fold_rows(partials: torch.Tensor, n_rows: int, C: int, out: Optional[torch.Tensor] = None,
+              tail_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[row, c] = sum_r partials[r, row, c] (fp32, fixed order); partials is [R, n_rows (+ tail rows), C] contiguous; `out` may
+    be a [n_rows, ld >= C] buffer whose extra columns are left alone (the padded packed layout of a weight gradient).
+    tail_out (fp32, contiguous, a multiple of C elements): the rows after the first n_rows are summed into it instead -- the
+    bias-gradient slabs that ride behind a weight gradient's slabs, folded by the same launch."""
     lib = _lib.load()
-    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() % (n_rows * C) == 0
-    R = partials.numel() // (n_rows * C)
+    tail_rows = 0 if tail_out is None else tail_out.numel() // C
+    total_rows = n_rows + tail_rows
+    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() % (total_rows * C) == 0
+    R = partials.numel() // (total_rows * C)
     if out is None:
         out = torch.empty(n_rows, C, dtype=torch.float32, device=partials.device)
     o2 = out.reshape(n_rows, -1)
     assert o2.dtype == torch.float32 and o2.stride(1) == 1 and o2.shape[1] >= C and (n_rows == 1 or o2.stride(0) == o2.shape[1])
     p = FoldRowsParams()
-    p.partials, p.out, p.R, p.n_rows, p.C, p.ld_out = partials.data_ptr(), o2.data_ptr(), R, n_rows, C, o2.shape[1]
+    p.partials, p.out, p.R, p.n_rows, p.C, p.ld_out = partials.data_ptr(), o2.data_ptr(), R, total_rows, C, o2.shape[1]
+    if tail_out is not None:
+        assert tail_out.dtype == torch.float32 and tail_out.is_contiguous() and tail_out.numel() == tail_rows * C
+        p.tail_out, p.tail_rows = tail_out.data_ptr(), tail_rows
     _lib.check(lib.aptp_fold_rows(ctypes.byref(p), _stream()), "aptp_fold_rows")
     return out
 
@@ -1184,20 +1192,27 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
     p.split_m = int(split_m) if split_m else lib.aptp_conv_wgrad_suggest_split(ctypes.byref(p))
     if out is not None:
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[:2]) == (N, KH * KW) and out.shape[2] >= C
-    db = torch.empty(p.split_m, N, dtype=torch.float32, device=x.device) if want_db else None
-    if want_db:
-        p.db = db.data_ptr()
     if p.split_m == 1:
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if want_db else None
+        if want_db:
+            p.db = db.data_ptr()
         res = out if out is not None else torch.empty(N, KH * KW, C, dtype=torch.float32, device=x.device)
         p.dw, p.ld_dw = res.data_ptr(), res.shape[2]
         _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
-        return (res, db.view(N)) if want_db else res
-    slabs = torch.empty(p.split_m, N * KH * KW, C, dtype=torch.float32, device=x.device)
+        return (res, db) if want_db else res
+    # slabs: [split][N*taps rows of C | ceil(N / C) more rows holding the slice's N bias-gradient sums]; ONE fold for both
+    rows, dbrows = N * KH * KW, ((N + C - 1) // C if want_db else 0)
+    slabs = torch.empty(p.split_m, rows + dbrows, C, dtype=torch.float32, device=x.device)
     p.dw = slabs.data_ptr()
+    tail = None
+    if want_db:
+        p.slab_stride = (rows + dbrows) * C
+        p.db, p.db_stride = slabs.data_ptr() + rows * C * 4, (rows + dbrows) * C
+        tail = torch.empty(dbrows * C, dtype=torch.float32, device=x.device)    # (entries past N: sums of unwritten slab floats, unused)
     _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
-    res = fold_rows(slabs, N * KH * KW, C, out=out)
+    res = fold_rows(slabs, rows, C, out=out, tail_out=tail)
     res = res if out is not None else res.view(N, KH * KW, C)
-    return (res, fold_rows(db, 1, N).view(N)) if want_db else res
+    return (res, tail[:N]) if want_db else res
 
 
 def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int) -> torch.Tensor:

@@ -394,6 +394,8 @@ typedef struct {
                                       kernel writes straight into a packed-layout gradient (pad columns are not touched) */
   float* db;                       /* optional fp32 [split_m, N]: per-slice column sums of dy = the bias gradient's slabs (the
                                       workgroups of input-channel block 0 sum the dy tiles they stage anyway) */
+  int64_t slab_stride;             /* elements between consecutive slices of dw; 0 = N*KH*KW*ld_dw */
+  int64_t db_stride;               /* elements between consecutive slices of db; 0 = N (both non-zero: db rows appended to dw's slabs) */
 } AptpWgradParams;
 int aptp_conv_wgrad_supported(const AptpWgradParams* p);
 int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p);
@@ -401,7 +403,11 @@ int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream);
 
 /* out[row][c] = sum over r < R of partials[r][row][c] (partials: fp32 [R][n_rows][C] contiguous; out: fp32 [n_rows][ld_out]); fixed order.
  * The slab sum of a split weight gradient (written into the padded packed layout) and the chunk sums of bias / affine gradients. */
-typedef struct { const float* partials; float* out; int32_t R, n_rows, C, ld_out; } AptpFoldRowsParams;
+typedef struct {
+  const float* partials; float* out; int32_t R, n_rows, C, ld_out;
+  float* tail_out; int32_t tail_rows;   /* optional: the LAST tail_rows of the n_rows go to tail_out (fp32 [tail_rows][C], contiguous)
+                                           instead of out -- a weight gradient's slabs and its bias gradient's slabs in one fold */
+} AptpFoldRowsParams;
 int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream);
 
 /* Mean squared error of two equally shaped activations, read where they lie (the loss terms of Pruner.step / FineTuner.step:

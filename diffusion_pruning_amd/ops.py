@@ -1172,6 +1172,7 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional
 # WGRAD_KERNEL=False forces the fallback everywhere (A/B timing, tests of both forms).
 # ------------------------------------------------------------------------------------------------------------------
 WGRAD_KERNEL = os.environ.get("APTP_WGRAD_KERNEL", "1") != "0"
+WGRAD_PARITY = True       # _wgrad_parity where its rule selects it (False: copies + GEMM for every resampling convolution)
 
 
 def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: Optional[int] = None,
@@ -1234,6 +1235,72 @@ def _im2col_T(x: torch.Tensor, KH: int, KW: int, stride: int, pad: int, ups: int
     return cols.reshape(KH * KW * C, B * Ho * Wo)
 
 
+_PARITY_IDX = {}
+
+
+def _wgrad_parity(x: torch.Tensor, dy: torch.Tensor, stride: int, ups: int, out: Optional[torch.Tensor], want_db: bool):
+    """Weight gradient of the six resampling convolutions of the U-Net (3x3 / stride 2 / pad 1 downsamplers; 3x3 on the
+    nearest-x2 upsampled input) through the stride-1 kernel.  Splitting the FINE grid by pixel parity turns either one into
+    four stride-1 correlations on the coarse grid:
+      stride 2:   x[2*oy + ky - 1] = x_p[oy + s],  (p, s) = (1, -1), (0, 0), (1, 0) for ky = 0, 1, 2   (x_p = rows of parity p)
+      upsample:   xu[2*i + a + ky - 1] = x[i + s], s = floor((a + ky - 1) / 2): (-1, 0, 0) for a = 0, (0, 0, 1) for a = 1
+    and the same along x, so dW[ky][kx] is a gather (stride 2) or a four-term sum (upsample) of taps of the four 3x3 results.
+    One parity-split copy of the fine operand replaces nine im2col copies, a transposed dy and a GEMM on them.  Returns None
+    when the coarse geometry is not handled by aptp_conv_wgrad."""
+    B, H, W, C = x.shape
+    N = dy.shape[-1]
+    dev = x.device
+    if stride == 2:
+        if H % 2 or W % 2 or tuple(dy.shape[1:3]) != (H // 2, W // 2):
+            return None
+        fine, coarse_other = x, dy
+    else:
+        if tuple(dy.shape[1:3]) != (2 * H, 2 * W):
+            return None
+        fine, coarse_other = dy, x
+    # the four parity planes of the fine operand, contiguous: [2, 2, B, h, w, ch]
+    Bf, Hf, Wf, Cf = fine.shape
+    planes = fine.reshape(Bf, Hf // 2, 2, Wf // 2, 2, Cf).permute(2, 4, 0, 1, 3, 5).contiguous()
+    key = (stride, ups, str(dev))
+    idx = _PARITY_IDX.get(key)
+    if idx is None:
+        if stride == 2:
+            par, sh = (1, 0, 1), (0, 1, 1)               # ky -> (parity of the source row, tap row of the stride-1 result)
+            dst = {(p_, q_): [] for p_ in (0, 1) for q_ in (0, 1)}
+            src = {(p_, q_): [] for p_ in (0, 1) for q_ in (0, 1)}
+            for ky in range(3):
+                for kx in range(3):
+                    dst[(par[ky], par[kx])].append(ky * 3 + kx)
+                    src[(par[ky], par[kx])].append(sh[ky] * 3 + sh[kx])
+            idx = {k: (torch.tensor(dst[k], device=dev), torch.tensor(src[k], device=dev)) for k in dst}
+        else:
+            ty = ((0, 1, 1), (1, 1, 2))                  # output-row parity a, ky -> tap row of the stride-1 result
+            idx = {(a, b): torch.tensor([ty[a][ky] * 3 + ty[b][kx] for ky in range(3) for kx in range(3)], device=dev)
+                   for a in (0, 1) for b in (0, 1)}
+        _PARITY_IDX[key] = idx
+    dW = torch.zeros(N, 9, C, dtype=torch.float32, device=dev) if stride != 2 else torch.empty(N, 9, C, dtype=torch.float32, device=dev)
+    db = None
+    for a in (0, 1):
+        for b in (0, 1):
+            xs, dys = (planes[a, b], coarse_other) if stride == 2 else (coarse_other, planes[a, b])
+            first = (a, b) == (0, 0)
+            r = _wgrad_direct(xs, dys, 3, 3, want_db=want_db and (first or stride != 2))
+            if r is None:
+                return None
+            if want_db and (first or stride != 2):
+                r, dbp = r
+                db = dbp if db is None else db + dbp      # upsample: the four parity planes of dy together are dy
+            if stride == 2:
+                d_i, s_i = idx[(a, b)]
+                dW[:, d_i] = r[:, s_i]
+            else:
+                dW += r[:, idx[(a, b)]]
+    if out is not None:
+        out[:, :, :C] = dW
+        dW = out
+    return (dW, db) if want_db else dW
+
+
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int = 1, pad: int = 0, ups: int = 0,
                out: Optional[torch.Tensor] = None, want_db: bool = False):
     """Weight gradient of y = conv(x, w): returns fp32 [N, KH*KW, C] (the packed-weight order, unpadded), or `out` (fp32
@@ -1247,6 +1314,15 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     C, N = x.shape[-1], dy.shape[-1]
     if WGRAD_KERNEL and stride == 1 and ups == 0 and KH == KW and pad == KH // 2 and x.shape[:3] == dy.shape[:3]:
         g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db)
+        if g is not None:
+            return g
+    # resampling convolutions: the parity split only pays where the fine grid is large and the weight small -- it runs the
+    # nine-tap kernel four times and uses 9 of the 36 tap results (tools/bench_wgrad_resample.py, us, parity vs copies+GEMM:
+    # upsample to 64x64 at 640 / 352 channels 449 vs 810 / 259 vs 396; every other resampling layer of SD-2.1 is 1.2-3.5x
+    # SLOWER that way, e.g. 704 vs 199 at 8x8 / 1280 channels), so the rule is narrow
+    if (WGRAD_KERNEL and WGRAD_PARITY and KH == 3 and KW == 3 and pad == 1 and x.dim() == 4 and stride == 1 and ups == 1
+            and dy.shape[0] * dy.shape[1] * dy.shape[2] >= 16384 and x.shape[-1] * dy.shape[-1] <= 640 * 640):
+        g = _wgrad_parity(x, dy, stride, ups, out, want_db)
         if g is not None:
             return g
     xt = _im2col_T(x, KH, KW, stride, pad, ups)                   # [K, M]

@@ -157,6 +157,16 @@ class DepthLerpParams(Structure):
     ]
 
 
+class AdamWItem(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("shadow", c_void_p), ("n", c_int64)]
+
+
+class AdamWParams(Structure):
+    _fields_ = [("items_dev", c_void_p), ("starts_dev", c_void_p), ("n_items", c_int32), ("total_blocks", c_int32),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+                ("step_dev", c_void_p)]
+
+
 class MseParams(Structure):
     _fields_ = [
         ("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64),
@@ -255,6 +265,8 @@ EXPORTS = [
     ("aptp_pack_dgrad", c_int, [POINTER(PackDgradParams), c_void_p]),
     ("aptp_pack_dgrad_blocks", c_int, [POINTER(PackDgradParams)]),
     ("aptp_pack_dgrad_many", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    ("aptp_adamw_blocks", c_int, [c_int64]),
+    ("aptp_adamw_many", c_int, [POINTER(AdamWParams), c_void_p]),
     ("aptp_mse_nblocks", c_int, [c_int64, c_int32]),
     ("aptp_mse", c_int, [POINTER(MseParams), c_void_p]),
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),

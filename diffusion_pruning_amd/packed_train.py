@@ -189,11 +189,13 @@ class PackedTrainer:
         return self
 
     @torch.no_grad()
-    def refresh_(self):
-        """shadows <- masters: one multi-tensor cast for the forward operands, ONE launch for all data-gradient operands
-        (ops.PackDgradBatch: a table of the weights in device memory, rebuilt when an operand appears or moves)"""
+    def refresh_(self, shadows_done: bool = False):
+        """shadows <- masters: one multi-tensor cast for the forward operands (skipped when the optimizer wrote them:
+        PackedAdamW), ONE launch for all data-gradient operands (ops.PackDgradBatch: a table of the weights in device memory,
+        rebuilt when an operand appears or moves)"""
         es = list(self.gemms.values())
-        torch._foreach_copy_([e.pw.w for e in es], [e.P.detach() for e in es])
+        if not shadows_done:
+            torch._foreach_copy_([e.pw.w for e in es], [e.P.detach() for e in es])
         pairs = [(e.pw, e.pwb) for e in es if e.pwb is not None]
         if not pairs:
             return
@@ -217,3 +219,72 @@ class PackedTrainer:
         for a in self.affines.values():
             a.export_()
         return self.model
+
+
+class PackedAdamW:
+    """torch.optim.AdamW's arithmetic over a PackedTrainer's state as ONE launch that also writes the bf16 operands
+    (csrc/optim.hip).  The gradient tensors must exist and stay where they are (``.grad`` of every parameter as left by the
+    captured backward of GraphedFineTunerStep: the graph re-writes the same addresses at every replay)."""
+
+    def __init__(self, trainer: PackedTrainer, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        import ctypes
+        from . import _lib
+        self.trainer, self.lr, self.betas, self.eps, self.weight_decay = trainer, lr, betas, eps, weight_decay
+        entries = []                                   # (parameter, bf16 shadow or None)
+        for e in trainer.gemms.values():
+            entries.append((e.P, e.pw.w))
+            if e.Pb is not None:
+                entries.append((e.Pb, None))
+        for a in trainer.affines.values():
+            entries += [(a.Pg, None), (a.Pb, None)]
+        entries = [(p, sh) for p, sh in entries if p.grad is not None]      # (entries no backward reaches have nothing to apply)
+        assert entries, "PackedAdamW: run one backward first (the gradient addresses go into the kernel's table)"
+        dev = entries[0][0].device
+        self.entries = entries
+        self.params = [p for p, _ in entries]
+        self.m = [torch.zeros_like(p.data) for p in self.params]
+        self.v = [torch.zeros_like(p.data) for p in self.params]
+        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.rebind_()
+
+    def rebind_(self):
+        """(re)build the kernel's table from the parameters' CURRENT gradient tensors (state is kept): once for a captured
+        backward, whose replays re-write the same addresses; before every step of an eager loop, whose backward allocates"""
+        from . import _lib
+        lib = _lib.load()
+        dev = self.params[0].device
+        self.grads = [p.grad for p in self.params]      # keeps the addresses in the table alive
+        items = (_lib.AdamWItem * len(self.entries))()
+        starts = [0]
+        for i, ((p, sh), m, v) in enumerate(zip(self.entries, self.m, self.v)):
+            g = p.grad
+            assert g is not None and g.is_contiguous() and p.data.is_contiguous() and g.dtype == torch.float32 and p.dtype == torch.float32
+            assert p.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and m.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+            it = items[i]
+            it.p, it.g, it.m, it.v, it.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+            if sh is not None:
+                assert sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() == p.numel() and sh.data_ptr() % 8 == 0
+                it.shadow = sh.data_ptr()
+            starts.append(starts[-1] + lib.aptp_adamw_blocks(p.numel()))
+        self.items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(dev)
+        self.n, self.total = len(self.entries), starts[-1]
+        return self
+
+    @torch.no_grad()
+    def step(self):
+        import ctypes
+        from . import _lib
+        for p, g in zip(self.params, self.grads):
+            assert p.grad is g, "PackedAdamW: a gradient tensor was replaced (its address is part of the kernel's table)"
+        lib = _lib.load()
+        q = _lib.AdamWParams()
+        q.items_dev, q.starts_dev, q.n_items, q.total_blocks = self.items.data_ptr(), self.starts.data_ptr(), self.n, self.total
+        q.lr, q.beta1, q.beta2, q.eps, q.weight_decay = self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay
+        q.step_dev = self.step_t.data_ptr()
+        _lib.check(lib.aptp_adamw_many(ctypes.byref(q), ops._stream()), "aptp_adamw_many")
+        self.step_t += 1.0
+        self.trainer.refresh_(shadows_done=True)
+
+    def state_dict(self):
+        return {"step": self.step_t.clone(), "exp_avg": [m.clone() for m in self.m], "exp_avg_sq": [v.clone() for v in self.v]}

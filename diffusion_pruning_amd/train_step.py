@@ -625,10 +625,11 @@ class FineTunerStep:
 
 
 class GraphedFineTunerStep(FineTunerStep):
-    """Expert fine-tuning with the trainable state in the kernels' layout (packed_train.PackedTrainer) and the whole step
-    replayed from ONE HIP graph: dense teacher forward, pruned student forward, the three loss terms (trainer.py:1730-1763),
-    backward incl. weight gradients, fused AdamW (trainer.py:1529-1540) and the refresh of the bf16 operands.  Nothing in the step touches the host, so the ~10^4 launches of the eager step (which is host-bound) cost
-    their device time only.  Same numbers as FineTunerStep on packed masters (tests/test_finetune_gpu.py)."""
+    """Expert fine-tuning with the trainable state in the kernels' layout (packed_train.PackedTrainer): dense teacher forward,
+    pruned student forward, the three loss terms (trainer.py:1730-1763) and the backward incl. weight gradients replayed from
+    ONE HIP graph, then AdamW (trainer.py:1529-1540) + the refresh of the bf16 operands as three launches
+    (packed_train.PackedAdamW).  The ~10^4 launches of the eager step (which is host-bound) cost their device time only.
+    Same numbers as FineTunerStep on packed masters with torch.optim.AdamW (tests/test_finetune_gpu.py)."""
 
     def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None,
                  lr: float = 1e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8):
@@ -667,10 +668,8 @@ class GraphedFineTunerStep(FineTunerStep):
         return (torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr).float()
 
     def capture(self, batch: dict, warmup_iters: int = 2, offload_masters: bool = False, _diag: str = ""):
-        """Build the packed trainable state, the fused AdamW and ONE HIP graph of the whole step (teacher forward, student
-        forward, losses, backward, optimizer, operand refresh) for this batch geometry.  The warm-up iterations that
-        PyTorch's whole-network capture needs are real optimizer steps; parameters and optimizer state are put back to
-        their values before them once the graph exists."""
+        """Build the packed trainable state, ONE HIP graph of teacher forward + student forward + losses + backward for this
+        batch geometry, and the one-launch AdamW over the gradients that graph leaves behind."""
         dev = batch["noisy_latents"].device
         st = {k: batch[k].clone() for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target")}
         if self.schedule.alphas_cumprod.device != dev:
@@ -685,11 +684,11 @@ class GraphedFineTunerStep(FineTunerStep):
             self.trainer.offload_masters_()
             torch.cuda.empty_cache()
         params = self.trainer.parameters()
-        self.optimizer = torch.optim.AdamW(params, fused=True, capturable=True, **self.opt_kw)
         out = {}
 
-        def one_step():
-            self.optimizer.zero_grad(set_to_none=True)
+        def fwd_bwd():
+            for p in params:
+                p.grad = None
             with torch.no_grad():
                 full_pred = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
             pred = self.student(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
@@ -699,37 +698,33 @@ class GraphedFineTunerStep(FineTunerStep):
             else:
                 total, diff, dist_l, blk = self._losses(pred, full_pred, st["snr_w"], st["target"])
             total.backward()
-            self.optimizer.step()
-            self.trainer.refresh_()
             out.update(total=total.detach(), diff=diff, dist=dist_l, blk=blk)
 
         import os as _os
         import sys as _sys
         _tr = (lambda m: print("[ft-capture]", m, file=_sys.stderr, flush=True)) if _os.environ.get("APTP_FT_TRACE") else (lambda m: None)
-        saved = [p.detach().clone() for p in params]
+        # warm-up (allocator, plan caches, autograd's stream anchors) runs forward + backward only: nothing to undo afterwards
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for i in range(warmup_iters):
-                one_step()
+                fwd_bwd()
                 _tr(f"warm-up {i} issued")
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         _tr("warm-up done")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            one_step()
+            fwd_bwd()
             _tr("captured body")
         _tr("capture ended")
-        with torch.no_grad():                       # undo the warm-up steps (the capture itself executes nothing)
-            for p, v in zip(params, saved):
-                p.copy_(v)
-            for stt in self.optimizer.state.values():
-                for t in stt.values():
-                    if torch.is_tensor(t):
-                        t.zero_()
-            self.trainer.refresh_()
-        del saved
+        # The optimizer is ONE launch over every trainable tensor and writes the bf16 operands in the same pass
+        # (packed_train.PackedAdamW, csrc/optim.hip); its table holds the addresses of the gradients the captured backward
+        # left in `.grad`, which every replay re-writes in place.  It runs right behind the graph, followed by the one-launch
+        # refresh of the data-gradient operands: three launches, no host work worth capturing.
+        from .packed_train import PackedAdamW
+        self.optimizer = PackedAdamW(self.trainer, lr=self.opt_kw["lr"], betas=self.opt_kw["betas"], eps=self.opt_kw["eps"],
+                                     weight_decay=self.opt_kw["weight_decay"])
         self._cap = dict(st=st, graph=graph, **out)
         return self
 
@@ -743,4 +738,5 @@ class GraphedFineTunerStep(FineTunerStep):
                 cap["st"][k].copy_(batch[k])
             cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
         cap["graph"].replay()
+        self.optimizer.step()
         return {"loss": cap["total"], "diff_loss": cap["diff"], "distillation_loss": cap["dist"], "block_loss": cap["blk"]}

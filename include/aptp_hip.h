@@ -410,6 +410,20 @@ typedef struct {
 } AptpFoldRowsParams;
 int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream);
 
+/* AdamW (torch.optim.AdamW arithmetic: decoupled weight decay, bias correction, fp32) over many tensors in ONE launch, writing
+ * the bf16 operand the GEMM kernels read in the same pass (the optimizer step of FineTuner.step, pdm/training/trainer.py:1529-1540,
+ * 1616-1619).  items_dev: n_items descriptors in DEVICE memory; p, g, m, v 16-byte aligned fp32 [n]; shadow optional bf16 [n]
+ * (8-byte aligned).  starts_dev: int32 [n_items + 1] prefix sums of aptp_adamw_blocks(n) in device memory; total_blocks =
+ * starts[n_items].  step_dev: fp32 device scalar = number of steps taken before this one (the caller increments it). */
+typedef struct { float* p; const float* g; float* m; float* v; void* shadow; int64_t n; } AptpAdamWItem;
+typedef struct {
+  const AptpAdamWItem* items_dev; const int32_t* starts_dev; int32_t n_items, total_blocks;
+  float lr, beta1, beta2, eps, weight_decay;
+  const float* step_dev;
+} AptpAdamWParams;
+int aptp_adamw_blocks(int64_t n);
+int aptp_adamw_many(const AptpAdamWParams* p, aptp_stream_t stream);
+
 /* Mean squared error of two equally shaped activations, read where they lie (the loss terms of Pruner.step / FineTuner.step:
  * pdm/training/trainer.py:1197-1225 diffusion MSE, output distillation, block distillation; :1729-1752 for the fine-tune step).
  * backward = 0: out[0] = mean((a - b)^2); partial: fp32 [aptp_mse_nblocks(rows, C)] scratch (every slot is written).

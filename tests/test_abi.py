@@ -48,7 +48,8 @@ def test_ctypes_layout_matches_the_c_header():
                "AptpLayerNormPgradParams": _lib.LayerNormPgradParams, "AptpDepthLerpParams": _lib.DepthLerpParams,
                "AptpWgradParams": _lib.WgradParams,
                "AptpFfTailParams": _lib.FfTailParams, "AptpFoldRowsParams": _lib.FoldRowsParams,
-               "AptpPackDgradParams": _lib.PackDgradParams, "AptpMseParams": _lib.MseParams}
+               "AptpPackDgradParams": _lib.PackDgradParams, "AptpMseParams": _lib.MseParams,
+               "AptpAdamWItem": _lib.AdamWItem, "AptpAdamWParams": _lib.AdamWParams}
     body = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, cls in structs.items():
         body.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1172,6 +1172,7 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional
 # WGRAD_KERNEL=False forces the fallback everywhere (A/B timing, tests of both forms).
 # ------------------------------------------------------------------------------------------------------------------
 WGRAD_KERNEL = os.environ.get("APTP_WGRAD_KERNEL", "1") != "0"
+WGRAD_SPLIT_TARGET = int(os.environ.get("APTP_WGRAD_SPLIT_TARGET", "0"))
 WGRAD_PARITY = True       # _wgrad_parity where its rule selects it (False: copies + GEMM for every resampling convolution)
 
 
@@ -1191,6 +1192,11 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
     _check_act(x, "conv_wgrad x")
     _check_act(dy, "conv_wgrad dy")
     p.split_m = int(split_m) if split_m else lib.aptp_conv_wgrad_suggest_split(ctypes.byref(p))
+    if not split_m and WGRAD_SPLIT_TARGET:
+        # (A/B of the pixel-range split: workgroups wanted per launch; the library's own rule is 512)
+        tiles = ((N + 63) // 64) * ((C + 63) // 64)
+        nsteps = (B * H * W + 31) // 32
+        p.split_m = max(1, min(-(-WGRAD_SPLIT_TARGET // tiles), max(1, nsteps // 4), 64))
     if out is not None:
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[:2]) == (N, KH * KW) and out.shape[2] >= C
     if p.split_m == 1:

@@ -143,6 +143,10 @@ class Rank:
         if self.dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.world == 1:                         # forced single-rank group without a launcher: fill in the rendezvous
+                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
             backend = args.backend or ("gloo" if self.cpu else "nccl")
             kw = {} if self.cpu else {"device_id": self.dev}
             dist.init_process_group(backend=backend, **kw)

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnBwdK p) {
       // sacc[r] = S^T[key = 64*tile + 32t + (r&3) + 8(r>>2) + 4hh][q]; rows past Lk hold K = 0, so their dS meets K^T = 0
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(sacc[r] * p.c - lse);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], p.c, -lse));   // raw v_exp_f32 (argument <= ~0, as in the forward)
         sacc[r] = pv * (dpacc[r] - delta);
       }
 #pragma unroll
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * g + i;
-          const float pv = exp2f(sacc[r] * p.c - lv[i]);
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], p.c, -lv[i]));   // raw v_exp_f32 (argument <= ~0)
           pacc[r] = pv;
           sacc[r] = pv * (dpacc[r] - dv[i]);
         }

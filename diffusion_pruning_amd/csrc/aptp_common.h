@@ -57,7 +57,24 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Standard normal CDF Phi(x) = 0.5 * erfc(-x / sqrt 2) with erfc by Abramowitz & Stegun 7.1.26 (erfc(z) = poly(t) * t * exp(-z^2),
+// t = 1 / (1 + 0.3275911 z), z >= 0; |error| <= 1.5e-7 in exact arithmetic, ~6e-7 in fp32): one reciprocal, one raw v_exp_f32
+// (argument <= 0) and six FMAs, against the ~30 instructions of libm's erff in loops that are VALU-bound (the GEGLU epilogue of
+// every feed-forward GEMM, the training GEGLU kernels).  The negative side is 0.5 * erfc(|z|) itself -- no 1 - (1 - tiny)
+// cancellation in GELU's tail.  Also hands back exp(-x^2 / 2) for the density in GELU's derivative.
+__device__ __forceinline__ float norm_cdf_f(float x, float* exp_mhx2) {
+  const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+  float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float half_erfc = 0.5f * poly * t * e;
+  if (exp_mhx2) *exp_mhx2 = e;
+  return x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return x * norm_cdf_f(x, nullptr); }
 
 // Next-launch weight prefetch (AptpConvGemmParams.prefetch / AptpGroupNormParams.prefetch): touch one dword per 64-byte line
 // of slice j of nper of the xcd-th eighth of [ptr, ptr + bytes) by LDS-DMA into a 256-byte scratch row (no VGPRs; results

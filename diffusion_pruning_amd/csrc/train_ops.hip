@@ -167,8 +167,9 @@ __global__ __launch_bounds__(256) void geglu_kernel(const GegluK p) {
             for (int e = 0; e < 8; ++e) {
               const float m = gm[pg][e];
               const float gmv = g[e] * m, hmv = h[e] * m;
-              const float cdf = 0.5f * (1.0f + erff(gmv * 0.70710678118654752440f));
-              const float pdf = 0.39894228040143267794f * __expf(-0.5f * gmv * gmv);
+              float e_half;                                        // exp(-gmv^2 / 2): the density's exponential
+              const float cdf = norm_cdf_f(gmv, &e_half);
+              const float pdf = 0.39894228040143267794f * e_half;
               const float gelu = gmv * cdf, dgelu = cdf + gmv * pdf;
               const float dhm = d[e] * gelu, dgm = d[e] * hmv * dgelu;
               dh[e] = dhm * m;

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (APTP_LIB=<file> loads another build of the same ABI: A/B timing of kernel changes on one box)
@@ -236,7 +236,7 @@ class AttentionBwdParams(Structure):
         ("dv", c_void_p), ("dv_stride_b", c_int64), ("dv_stride_l", c_int64),
         ("lse", c_void_p), ("delta", c_void_p),
         ("B", c_int32), ("heads", c_int32), ("Lq", c_int32), ("Lk", c_int32),
-        ("scale", c_float),
+        ("scale", c_float), ("q_split", c_int32), ("workspace", c_void_p),
     ]
 
 
@@ -272,6 +272,8 @@ EXPORTS = [
     ("aptp_groupnorm_bwd", c_int, [POINTER(GroupNormBwdParams), c_void_p]),
     ("aptp_layernorm_bwd", c_int, [POINTER(LayerNormBwdParams), c_void_p]),
     ("aptp_attention_bwd", c_int, [POINTER(AttentionBwdParams), c_void_p]),
+    ("aptp_attention_bwd_q_split", c_int, [POINTER(AttentionBwdParams)]),
+    ("aptp_attention_bwd_workspace_bytes", c_size_t, [POINTER(AttentionBwdParams), c_int32]),
     ("aptp_colsum", c_int, [POINTER(ColsumParams), c_void_p]),
     ("aptp_layernorm_pgrad", c_int, [POINTER(LayerNormPgradParams), c_void_p]),
     ("aptp_unet_prologue", c_int, [POINTER(UnetPrologueParams), c_void_p]),

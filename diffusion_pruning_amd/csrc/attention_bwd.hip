@@ -29,6 +29,7 @@ struct AttnBwdK {
   const float* lse; float* delta;   // [B, H, Lq]
   int B, H, Lq, Lk;
   float scale, c;                   // c = scale * log2(e)
+  float* part; int nsplit;          // dK/dV kernel: query range split over nsplit workgroups, fp32 partials [nsplit][B][H][Lk][128]
 };
 
 __device__ __forceinline__ int perm16(int idx) {   // o = 8a + 4h + c  ->  8h + 4a + c inside each group of 16
@@ -194,7 +195,9 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int nkt = (p.Lk + 127) / 128;
+  const int kt = blockIdx.x % nkt, sp = blockIdx.x / nkt;       // key tile, slice of the query range
+  const int k0 = kt * 128 + wave * 32;
   const int krow = k0 + lk;
   const bool kok = krow < p.Lk;
   const int kc = kok ? krow : p.Lk - 1;
@@ -236,9 +239,10 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkacc[u][r] = 0.f; dvacc[u][r] = 0.f; }
 
-  const int ntiles = (p.Lq + 63) / 64;
-  load_q(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  const int ntiles_all = (p.Lq + 63) / 64;
+  const int tile0 = (int)(((int64_t)ntiles_all * sp) / p.nsplit), ntiles = (int)(((int64_t)ntiles_all * (sp + 1)) / p.nsplit);
+  if (tile0 < ntiles) load_q(tile0);
+  for (int tile = tile0; tile < ntiles; ++tile) {
     __syncthreads();
     stage_tile(Qs, Qt, qr[0], qr[1], pair, chunk);
     stage_tile(Ds, Dt, dr[0], dr[1], pair, chunk);
@@ -284,7 +288,19 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
       }
     }
   }
-  if (kok) {
+  if (kok && p.nsplit > 1) {
+    // partial sums of this slice of the query range (fp32, dK already scaled): [sp][b][h][key][dk 64 | dv 64]
+    float* pp = p.part + ((((int64_t)sp * p.B + b) * p.H + h) * p.Lk + krow) * 128;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * u + 8 * g + 4 * hh;
+        *reinterpret_cast<float4*>(pp + d) = make_float4(dkacc[u][4 * g + 0] * p.scale, dkacc[u][4 * g + 1] * p.scale,
+                                                         dkacc[u][4 * g + 2] * p.scale, dkacc[u][4 * g + 3] * p.scale);
+        *reinterpret_cast<float4*>(pp + 64 + d) = make_float4(dvacc[u][4 * g + 0], dvacc[u][4 * g + 1], dvacc[u][4 * g + 2], dvacc[u][4 * g + 3]);
+      }
+  } else if (kok) {
     __bf16* dkp = p.dk + (int64_t)b * p.dksb + (int64_t)krow * p.dksl + (int64_t)h * 64;
     __bf16* dvp = p.dv + (int64_t)b * p.dvsb + (int64_t)krow * p.dvsl + (int64_t)h * 64;
 #pragma unroll
@@ -303,7 +319,50 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
   }
 }
 
+// dK, dV = sum over the query slices of the partials (slice order: deterministic); one thread per (b, h, key, 4 channels of 128)
+__global__ __launch_bounds__(256) void attn_dkdv_fold_kernel(const AttnBwdK p) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.H * p.Lk * 32;
+  if (idx >= total) return;
+  const int c4 = (int)(idx & 31);
+  const int64_t row = idx >> 5;                                   // (b * H + h) * Lk + key
+  const int key = (int)(row % p.Lk);
+  const int64_t bh = row / p.Lk;
+  const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+  const int64_t slab = (int64_t)p.B * p.H * p.Lk * 128;
+  const float* src = p.part + row * 128 + c4 * 4;
+  float4 a = *reinterpret_cast<const float4*>(src);
+  for (int s = 1; s < p.nsplit; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(src + s * slab);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+  uint2 w; w.x = pack_bf16x2(a.x, a.y); w.y = pack_bf16x2(a.z, a.w);
+  __bf16* dst = c4 < 16 ? p.dk + (int64_t)b * p.dksb + (int64_t)key * p.dksl + (int64_t)h * 64 + c4 * 4
+                        : p.dv + (int64_t)b * p.dvsb + (int64_t)key * p.dvsl + (int64_t)h * 64 + (c4 - 16) * 4;
+  *reinterpret_cast<uint2*>(dst) = w;
+}
+
 }  // namespace
+
+// Few keys (cross-attention: 77) leave the dK/dV kernel with one key tile per (b, head) -- 20 workgroups sweeping 4096 queries
+// each at SD-2.1 level 64 (152 us against 15 us for the forward).  The query range is then split over `q_split` workgroups.
+extern "C" int aptp_attention_bwd_q_split(const AptpAttentionBwdParams* p) {
+  if (!p || p->Lk <= 0 || p->Lq <= 0) return 1;
+  const int64_t wgs = (int64_t)((p->Lk + 127) / 128) * p->heads * p->B;
+  const int ntiles = (p->Lq + 63) / 64;
+  // measured (tools/bench_attn_bwd.py, B = 4, 77 keys; us for 1 / 2 / 4 / 8 / 16 slices): 4096 queries x 5 heads 156 / 96 / 65 / 52 / 57;
+  // 1024 x 10 heads 51 / 39 / 33 / 37 / 42; 256 x 20 heads 23 / 24 / 31: about 160 workgroups, and only for long query ranges
+  if (wgs >= 128 || ntiles < 16) return 1;
+  int64_t s = (160 + wgs / 2) / wgs;
+  const int cap = ntiles / 2;                                     // at least two query tiles per slice
+  s = s > cap ? cap : s;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" size_t aptp_attention_bwd_workspace_bytes(const AptpAttentionBwdParams* p, int32_t q_split) {
+  if (!p || q_split <= 1) return 0;
+  return (size_t)q_split * p->B * p->heads * p->Lk * 128 * sizeof(float);
+}
 
 extern "C" int aptp_attention_bwd(const AptpAttentionBwdParams* p, aptp_stream_t stream) {
   APTP_CHECK(p && p->q && p->k && p->v && p->o && p->dout && p->dq && p->dk && p->dv && p->lse && p->delta, "attention_bwd: null pointer");
@@ -326,11 +385,19 @@ extern "C" int aptp_attention_bwd(const AptpAttentionBwdParams* p, aptp_stream_t
   k.lse = p->lse; k.delta = p->delta;
   k.B = p->B; k.H = p->heads; k.Lq = p->Lq; k.Lk = p->Lk;
   k.scale = p->scale; k.c = p->scale * 1.44269504088896340736f;
+  k.nsplit = p->q_split > 1 ? p->q_split : 1;
+  k.part = (float*)p->workspace;
+  APTP_CHECK(k.nsplit == 1 || (p->workspace && ((uintptr_t)p->workspace % 16) == 0 && k.nsplit <= (p->Lq + 63) / 64),
+             "attention_bwd: q_split needs a 16-byte aligned workspace of aptp_attention_bwd_workspace_bytes and <= the query tiles");
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = (int64_t)p->B * p->Lq * p->heads;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
   hipLaunchKernelGGL(attn_dq_kernel, dim3((p->Lq + 127) / 128, p->heads, p->B), dim3(256), 0, s, k);
-  hipLaunchKernelGGL(attn_dkdv_kernel, dim3((p->Lk + 127) / 128, p->heads, p->B), dim3(256), 0, s, k);
+  hipLaunchKernelGGL(attn_dkdv_kernel, dim3(((p->Lk + 127) / 128) * k.nsplit, p->heads, p->B), dim3(256), 0, s, k);
+  if (k.nsplit > 1) {
+    const int64_t n = (int64_t)p->B * p->heads * p->Lk * 32;
+    hipLaunchKernelGGL(attn_dkdv_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k);
+  }
   APTP_LAUNCH_CHECK();
   return APTP_OK;
 }

@@ -1145,8 +1145,12 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     return dx
 
 
-def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional[float] = None):
-    """dq/dk/dv are preallocated bf16 views (e.g. column slices of one fused gradient buffer), written in place."""
+ATTN_BWD_Q_SPLIT = True      # False: never split the dK/dV kernel's query range (A/B timing, tests of both forms)
+
+
+def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional[float] = None, q_split: Optional[int] = None):
+    """dq/dk/dv are preallocated bf16 views (e.g. column slices of one fused gradient buffer), written in place.
+    q_split: slices of the query range in the dK/dV kernel (None: the library's rule -- only where few keys leave the chip idle)"""
     lib = _lib.load()
     B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
     delta = torch.empty(B, heads, Lq, dtype=torch.float32, device=q.device)
@@ -1159,6 +1163,12 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional
     p.lse, p.delta = lse.data_ptr(), delta.data_ptr()
     p.B, p.heads, p.Lq, p.Lk = B, heads, Lq, Lk
     p.scale = (1.0 / 8.0) if scale is None else scale
+    if q_split is None:
+        q_split = lib.aptp_attention_bwd_q_split(ctypes.byref(p)) if ATTN_BWD_Q_SPLIT else 1
+    ws = None
+    if q_split > 1:
+        ws = torch.empty(lib.aptp_attention_bwd_workspace_bytes(ctypes.byref(p), q_split), dtype=torch.uint8, device=q.device)
+        p.q_split, p.workspace = q_split, ws.data_ptr()
     _lib.check(lib.aptp_attention_bwd(ctypes.byref(p), _stream()), "aptp_attention_bwd")
     return dq, dk, dv
 

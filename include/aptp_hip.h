@@ -507,7 +507,12 @@ typedef struct {
   const float* lse; float* delta;
   int32_t B, heads, Lq, Lk;
   float scale;
+  int32_t q_split;   /* dK/dV: split the query range over this many workgroups (0 / 1 = off; aptp_attention_bwd_q_split suggests
+                        it: few keys -- cross-attention's 77 -- leave one key tile per (b, head)), fp32 partials folded in slice order */
+  void* workspace;   /* aptp_attention_bwd_workspace_bytes(p, q_split) bytes, 16-byte aligned, when q_split > 1 */
 } AptpAttentionBwdParams;
+int aptp_attention_bwd_q_split(const AptpAttentionBwdParams* p);
+size_t aptp_attention_bwd_workspace_bytes(const AptpAttentionBwdParams* p, int32_t q_split);
 int aptp_attention_bwd(const AptpAttentionBwdParams* p, aptp_stream_t stream);
 
 const char* aptp_last_error(void);

@@ -158,6 +158,17 @@ def test_attention_bwd(ops, cuda, case):
     assert rel_l2(dv.float().cpu(), v.grad) <= 1e-2
     assert rel_l2(dq.float().cpu(), q.grad) <= 1.5e-2
     assert rel_l2(dk.float().cpu(), k.grad) <= 1.5e-2
+    # dK/dV with the query range split over workgroups (the rule switches it on by itself where few keys leave the chip idle:
+    # cross-attention); forced here for every case with enough query tiles: same sums up to the fp32 association, deterministic
+    if (Lq + 63) // 64 >= 3:
+        dq2, dk2, dv2 = (torch.full_like(t, 7.0) for t in (qd, kd, vd))
+        ops.attention_bwd(qd, kd, vd, od, do.bfloat16().to(cuda), lse, h, dq2, dk2, dv2, q_split=3)
+        assert torch.equal(dq2, dq)
+        assert rel_l2(dk2.float(), dk.float()) <= 4e-3 and rel_l2(dv2.float(), dv.float()) <= 4e-3
+        assert rel_l2(dv2.float().cpu(), v.grad) <= 1e-2 and rel_l2(dk2.float().cpu(), k.grad) <= 1.5e-2
+        dk3, dv3 = torch.empty_like(dk2), torch.empty_like(dv2)
+        ops.attention_bwd(qd, kd, vd, od, do.bfloat16().to(cuda), lse, h, torch.empty_like(dq2), dk3, dv3, q_split=3)
+        assert torch.equal(dk3, dk2) and torch.equal(dv3, dv2)
 
 
 @pytest.mark.parametrize("B,dB,HW,C,wide", [(4, 2, 64, 64, 0), (2, 2, 1024, 320, 320), (4, 1, 256, 1280, 1280), (2, 1, 30, 2560, 0)])

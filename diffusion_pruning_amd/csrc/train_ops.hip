@@ -24,7 +24,7 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return q;
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // v_rcp_f32, no IEEE division
 
 // ------------------------------------------------------------------------------------------------------------
 // Row-chunk layout shared by the streaming kernels below: grid (nchunk, B); block 256 threads; thread -> octet
@@ -392,28 +392,38 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdK p) {
   }
   if (active) {
     const int64_t row0 = (int64_t)b * k.HW;
-    for (int r = r0 + rl; r < r1; r += k.RPAR) {
+    // two rows per trip: the four 16-byte loads of a (page, row pair) are issued before any of the arithmetic
+    for (int r = r0 + rl; r < r1; r += 2 * k.RPAR) {
+      const int rb = r + k.RPAR;
+      const bool two = rb < r1;
 #pragma unroll
       for (int pg = 0; pg < NP; ++pg) {
         const int o = ot + pg * 256;
         if (o < k.CO) {
-          const u32x4 qx = *reinterpret_cast<const u32x4*>(p.x + (row0 + r) * p.ldx + o * 8);
-          const u32x4 qd = *reinterpret_cast<const u32x4*>(p.dy + (row0 + r) * p.lddy + o * 8);
-          float x[8], d[8], dxv[8];
-          unpack8(qx, x); unpack8(qd, d);
+          u32x4 qx[2], qd[2];
+          qx[0] = *reinterpret_cast<const u32x4*>(p.x + (row0 + r) * p.ldx + o * 8);
+          qd[0] = *reinterpret_cast<const u32x4*>(p.dy + (row0 + r) * p.lddy + o * 8);
+          qx[1] = two ? *reinterpret_cast<const u32x4*>(p.x + (row0 + rb) * p.ldx + o * 8) : (u32x4){0u, 0u, 0u, 0u};
+          qd[1] = two ? *reinterpret_cast<const u32x4*>(p.dy + (row0 + rb) * p.lddy + o * 8) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float xh = (x[e] - mu[pg][e]) * rs[pg][e];
-            float dz = d[e];
-            if (p.silu) {
-              const float z = xh * ga[pg][e] + be[pg][e];
-              const float sg = sigmoid_f(z);
-              dz *= sg * (1.0f + z * (1.0f - sg));
+          for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            float x[8], d[8], dxv[8];
+            unpack8(qx[h], x); unpack8(qd[h], d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xh = (x[e] - mu[pg][e]) * rs[pg][e];
+              float dz = d[e];
+              if (p.silu) {
+                const float z = xh * ga[pg][e] + be[pg][e];
+                const float sg = sigmoid_f(z);
+                dz *= sg * (1.0f + z * (1.0f - sg));
+              }
+              if (APPLY) dxv[e] = rs[pg][e] * (dz * ga[pg][e] - m1[pg][e] - xh * m2[pg][e]);
+              else { a1[pg][e] += dz; a2v[pg][e] += dz * xh; }
             }
-            if (APPLY) dxv[e] = rs[pg][e] * (dz * ga[pg][e] - m1[pg][e] - xh * m2[pg][e]);
-            else { a1[pg][e] += dz; a2v[pg][e] += dz * xh; }
+            if (APPLY) *reinterpret_cast<u32x4*>(p.dx + (row0 + (h ? rb : r)) * p.lddx + o * 8) = pack8(dxv);
           }
-          if (APPLY) *reinterpret_cast<u32x4*>(p.dx + (row0 + r) * p.lddx + o * 8) = pack8(dxv);
         }
       }
     }

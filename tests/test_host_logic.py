@@ -414,3 +414,20 @@ def test_one_host_draw_equals_the_per_block_gumbel_draws(fixed):
         after_got = torch.rand(3)
         assert torch.equal(ref, got)
         assert torch.equal(after_ref, after_got)
+
+
+def test_scratch_domain_is_thread_local_and_restores():
+    """ops.scratch_domain: the key under which split-K counters / scratch are looked up (graphs that replay concurrently are
+    captured under different domains); nesting restores the outer name, other threads are not affected"""
+    import threading
+    from diffusion_pruning_amd import ops
+    assert ops._domain() is None
+    seen = {}
+    with ops.scratch_domain("teacher"):
+        assert ops._domain() == "teacher"
+        t = threading.Thread(target=lambda: seen.setdefault("other", ops._domain()))
+        t.start(); t.join()
+        with ops.scratch_domain("inner"):
+            assert ops._domain() == "inner"
+        assert ops._domain() == "teacher"
+    assert ops._domain() is None and seen["other"] is None

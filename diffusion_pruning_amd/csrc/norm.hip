@@ -364,6 +364,7 @@ struct GnG {
   int gpb;        // groups per workgroup (1, 2, 4 or 8)
   int TPR, RPAR;  // chunks per slab row (= gpb*cg/8 <= 32), rows in parallel (NT / TPR)
   int R256;       // rows folded per LDS round (256 / TPR)
+  float* stats_out; int nchunk;   // optional [B, nchunk, G, 2] (sum, sumsq) partials for the backward: chunk 0 = the sums, rest 0
 };
 
 template <int U, int NT>
@@ -456,6 +457,11 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
       var = var < 0.f ? 0.f : var;
       mean_s[lg] = mean;
       rstd_s[lg] = rsqrtf(var + p.eps);
+      if (p.stats_out) {                       // what the three-launch form leaves for groupnorm_bwd, in its layout
+        float2* st = reinterpret_cast<float2*>(p.stats_out) + (int64_t)b * p.nchunk * p.G + (g0 + lg);
+        st[0] = make_float2(a, a2);
+        for (int c = 1; c < p.nchunk; ++c) st[(int64_t)c * p.G] = make_float2(0.f, 0.f);
+      }
     }
   }
   __syncthreads();
@@ -609,7 +615,7 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   k.TPR = CO < 256 ? CO : 256;
   k.RPAR = 256 / k.TPR;
   hipStream_t s = (hipStream_t)stream;
-  APTP_CHECK(p->variant >= 0 && p->variant <= 3, "groupnorm: variant %d", p->variant);
+  APTP_CHECK(p->variant >= 0 && p->variant <= 4, "groupnorm: variant %d", p->variant);
   // group-owner single launch: gpb = fewest groups whose channels fill whole 16-byte chunks
   int gpb = 1;
   while ((gpb * k.cg) % 8 != 0) gpb *= 2;   // cg * 8 is always a multiple of 8, so gpb <= 8
@@ -619,6 +625,7 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
     q.x = k.x; q.ldx = k.ldx; q.y = k.y; q.ldy = k.ldy; q.B = k.B; q.HW = k.HW; q.C = k.C; q.G = k.G; q.cg = k.cg;
     q.gamma = k.gamma; q.beta = k.beta; q.eps = k.eps; q.silu = k.silu;
     q.gpb = gpb; q.TPR = tpr; q.R256 = 256 / tpr;
+    q.stats_out = p->variant == 4 ? k.ws : nullptr; q.nchunk = k.nchunk;
     const dim3 grid((k.G + gpb - 1) / gpb, k.B);
     bool done = false;
     q.RPAR = 256 / tpr;

@@ -331,6 +331,7 @@ def _tile_counters(device):
 # workgroups) measured much SLOWER on MI355X (149.5 vs 167.4 steps/s: 64 statistics workgroups cannot stream a level-64
 # map fast enough), so it stays opt-in.
 GN_DEFAULT_VARIANT = 0
+GN_STATS_ONE_LAUNCH = True     # keep_stats on the small maps through the one-launch kernel (False: always three launches; A/B, tests)
 
 # AptpAttentionParams.variant for every launch (1 = staggered wave groups: A/B timing, tests of both forms)
 ATTN_VARIANT = 0
@@ -638,8 +639,8 @@ def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
               C: Optional[int] = None, out: Optional[torch.Tensor] = None, keep_stats: bool = False, variant: int = 0):
     """GroupNorm(+SiLU) of a [B,H,W,Cp] tensor over its first C real channels (Cp = roundup8(C)).
-    keep_stats: also return the fp32 [B, nchunk, groups, 2] statistics partials (needed by groupnorm_bwd; forces the
-    three-launch form).  variant: see AptpGroupNormParams in include/aptp_hip.h."""
+    keep_stats: also return the fp32 [B, nchunk, groups, 2] statistics partials (needed by groupnorm_bwd; variant 4: one
+    launch on the small maps, three elsewhere).  variant: see AptpGroupNormParams in include/aptp_hip.h."""
     lib = _lib.load()
     _check_act(x, "groupnorm x")
     B, H, W, Cp = x.shape
@@ -658,7 +659,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
         ws_full = torch.empty(B * (nch + 1) * groups * 2, dtype=torch.float32, device=x.device)
         ws = ws_full[:B * nch * groups * 2].view(B, nch, groups, 2)
         p.workspace = ws_full.data_ptr()
-        p.variant = 1
+        p.variant = 4 if GN_STATS_ONE_LAUNCH else 1
         _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm")
         return out, ws
     else:

@@ -215,9 +215,11 @@ typedef struct {
   float eps;
   int32_t silu;
   void* workspace;
-  /* 0 = auto; 1 = three launches (stats, finalise, apply): the only form that fills the workspace partials
-   * aptp_groupnorm_bwd consumes; 2 = one launch, each workgroup owning whole groups of one sample (small maps);
-   * 3 = two launches: at most 16 coarse statistics chunks, folded by every apply workgroup (no finalise launch). */
+  /* 0 = auto; 1 = three launches (stats, finalise, apply), which fill the workspace partials aptp_groupnorm_bwd consumes;
+   * 2 = one launch, each workgroup owning whole groups of one sample (small maps);
+   * 3 = two launches: at most 16 coarse statistics chunks, folded by every apply workgroup (no finalise launch);
+   * 4 = auto WITH those partials: the small maps still take one launch (the owning workgroup writes its groups' sums into
+   *     chunk 0 and zeros into the other chunks), everything else the three-launch form. */
   int32_t variant;
   /* optional, three-launch form only: >= B int32 words, ZERO on entry and left zero.  The last statistics workgroup of
    * each sample then folds the partials itself (write-through partial stores, one agent-scope acquire) and the

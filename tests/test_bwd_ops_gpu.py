@@ -69,6 +69,17 @@ def test_groupnorm_bwd(ops, cuda, case):
     assert rel_l2(yk.float().cpu().permute(0, 3, 1, 2), y.detach()) <= 4e-3
     dx = ops.groupnorm_bwd(xd, nhwc(dy).bfloat16().to(cuda), gamma.to(cuda), beta.to(cuda), G, eps, silu, stats)
     assert rel_l2(dx.float().cpu().permute(0, 3, 1, 2), x.grad) <= TOL
+    # keep_stats on a small map = the one-launch kernel writing the sums into chunk 0 of the partials; the three-launch form
+    # spreads them over the chunks: same totals, same output, same backward
+    ops.GN_STATS_ONE_LAUNCH = False
+    try:
+        y3, stats3 = ops.groupnorm(xd, gamma.to(cuda), beta.to(cuda), G, eps, silu, keep_stats=True)
+    finally:
+        ops.GN_STATS_ONE_LAUNCH = True
+    assert stats.shape == stats3.shape and rel_l2(stats.sum(1), stats3.sum(1)) <= 1e-5
+    assert rel_l2(yk.float(), y3.float()) <= 2e-3
+    dx3 = ops.groupnorm_bwd(xd, nhwc(dy).bfloat16().to(cuda), gamma.to(cuda), beta.to(cuda), G, eps, silu, stats3)
+    assert rel_l2(dx.float(), dx3.float()) <= 2e-3
 
 
 @pytest.mark.parametrize("rows,C", [(33, 64), (128, 320), (65, 1280)])

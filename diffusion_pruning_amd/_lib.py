@@ -250,6 +250,7 @@ EXPORTS = [
     ("aptp_conv_gemm_colstat_rows", c_int, [POINTER(ConvGemmParams)]),
     ("aptp_groupnorm", c_int, [POINTER(GroupNormParams), c_void_p]),
     ("aptp_groupnorm_nchunk", c_int, [c_int]),
+    ("aptp_rows_nchunk", c_int, [c_int]),
     ("aptp_groupnorm_workspace_bytes", c_int64, [POINTER(GroupNormParams)]),
     ("aptp_layernorm", c_int, [POINTER(LayerNormParams), c_void_p]),
     ("aptp_attention", c_int, [POINTER(AttentionParams), c_void_p]),

@@ -590,6 +590,15 @@ extern "C" int aptp_groupnorm_nchunk(int HW) {
   return n;
 }
 
+// Row chunks of the kernels that have no batch dimension in their grid (layernorm_pgrad; colsum with batch == 1): the cap of the
+// per-sample rule (128) would put 128 workgroups on 16384 rows -- half the chip, 128 rows each
+extern "C" int aptp_rows_nchunk(int rows) {
+  int n = rows <= 1024 ? rows / 4 : rows / 16;
+  if (n < 1) n = 1;
+  if (n > 1024) n = 1024;
+  return n;
+}
+
 extern "C" int64_t aptp_groupnorm_workspace_bytes(const AptpGroupNormParams* p) {
   if (!p) return 0;
   // [B, nchunk, G, 2] partials followed by [B, G, 2] finalised (mean, rstd)

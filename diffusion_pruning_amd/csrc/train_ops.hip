@@ -810,8 +810,9 @@ extern "C" int aptp_colsum(const AptpColsumParams* p, aptp_stream_t stream) {
   APTP_CHECK(p->rows > 0 && p->C > 0 && p->C % 8 == 0 && p->C <= 6144 && p->ldx % 8 == 0 && ALIGN16(p->x), "colsum: C multiple of 8 (<= 6144), ld multiple of 8");
   ColsumK k;
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.rows = p->rows; k.C = p->C; k.CO = p->C / 8;
-  k.nchunk = aptp_groupnorm_nchunk(p->rows); k.TPR = k.CO < 256 ? k.CO : 256; k.RPAR = 256 / k.TPR; k.partial = p->partial;
   k.batch = p->batch > 0 ? p->batch : 1;
+  k.nchunk = k.batch > 1 ? aptp_groupnorm_nchunk(p->rows) : aptp_rows_nchunk(p->rows);
+  k.TPR = k.CO < 256 ? k.CO : 256; k.RPAR = 256 / k.TPR; k.partial = p->partial;
   APTP_CHECK(k.batch <= 65535, "colsum: batch");
   dim3 grid(k.nchunk, k.batch);
   hipStream_t s = (hipStream_t)stream;
@@ -827,7 +828,7 @@ extern "C" int aptp_layernorm_pgrad(const AptpLayerNormPgradParams* p, aptp_stre
   APTP_CHECK(p->rows > 0 && p->C > 0 && p->C % 8 == 0 && p->C <= 2048 && p->ldx % 8 == 0 && p->lddy % 8 == 0 && ALIGN16(p->x) && ALIGN16(p->dy), "layernorm_pgrad: C multiple of 8 (<= 2048)");
   LnPgK k;
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy;
-  k.rows = p->rows; k.C = p->C; k.CO = p->C / 8; k.nchunk = aptp_groupnorm_nchunk(p->rows); k.eps = p->eps; k.partial = p->partial;
+  k.rows = p->rows; k.C = p->C; k.CO = p->C / 8; k.nchunk = aptp_rows_nchunk(p->rows); k.eps = p->eps; k.partial = p->partial;
   dim3 grid(k.nchunk);
   hipStream_t s = (hipStream_t)stream;
   switch ((k.CO + 63) / 64) {

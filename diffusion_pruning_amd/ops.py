@@ -1108,7 +1108,7 @@ def layernorm_pgrad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5):
     lib = _lib.load()
     B, L, C, ldx = _rows(x)
     _, _, _, lddy = _rows(dy)
-    nchunk = lib.aptp_groupnorm_nchunk(B * L)
+    nchunk = lib.aptp_rows_nchunk(B * L)
     part = torch.empty(nchunk, C, 2, dtype=torch.float32, device=x.device)
     p = LayerNormPgradParams()
     p.x, p.ldx, p.dy, p.lddy, p.rows, p.C, p.eps, p.partial = x.data_ptr(), ldx, dy.data_ptr(), lddy, B * L, C, eps, part.data_ptr()
@@ -1125,7 +1125,7 @@ def colsum(x: torch.Tensor, per_sample: bool = False) -> torch.Tensor:
     B = x.shape[0] if per_sample else 1
     x2 = x.reshape(-1, C)
     rows = x2.shape[0] // B
-    nchunk = lib.aptp_groupnorm_nchunk(rows)
+    nchunk = lib.aptp_groupnorm_nchunk(rows) if B > 1 else lib.aptp_rows_nchunk(rows)
     part = torch.empty(nchunk, B, C, dtype=torch.float32, device=x.device)
     p = ColsumParams()
     p.x, p.ldx, p.rows, p.C, p.partial, p.batch = x2.data_ptr(), (x2.stride(0) if x2.shape[0] > 1 else C), rows, C, part.data_ptr(), B

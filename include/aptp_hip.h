@@ -233,6 +233,7 @@ typedef struct {
 
 int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream);
 int aptp_groupnorm_nchunk(int HW);
+int aptp_rows_nchunk(int rows);   /* row chunks of the kernels without a batch dimension (aptp_layernorm_pgrad, aptp_colsum with batch <= 1) */
 int64_t aptp_groupnorm_workspace_bytes(const AptpGroupNormParams* p);
 
 /*
@@ -481,11 +482,12 @@ typedef struct {
 int aptp_layernorm_bwd(const AptpLayerNormBwdParams* p, aptp_stream_t stream);
 
 /* Column sums of `batch` (0 = 1) consecutive bf16 [rows, C] matrices (bias gradients; batch > 1: per-sample sums for the
- * gradient of a per-sample output bias): partial fp32 [aptp_groupnorm_nchunk(rows), batch, C]. */
+ * gradient of a per-sample output bias): partial fp32 [nchunk, batch, C], nchunk = aptp_groupnorm_nchunk(rows) for batch > 1,
+ * aptp_rows_nchunk(rows) otherwise. */
 typedef struct { const void* x; int64_t ldx; int32_t rows, C; float* partial; int32_t batch; } AptpColsumParams;
 int aptp_colsum(const AptpColsumParams* p, aptp_stream_t stream);
 
-/* LayerNorm affine-parameter gradient partials: fp32 [aptp_groupnorm_nchunk(rows), C, 2] = (sum dy, sum dy*xhat). */
+/* LayerNorm affine-parameter gradient partials: fp32 [aptp_rows_nchunk(rows), C, 2] = (sum dy, sum dy*xhat). */
 typedef struct {
   const void* x; int64_t ldx;
   const void* dy; int64_t lddy;

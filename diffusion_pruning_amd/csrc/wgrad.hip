@@ -16,6 +16,7 @@
 // two LDS buffers, one barrier per step).  The pixel range is split over `split_m` workgroups (fp32 slabs, summed by the
 // caller in a fixed order: deterministic).
 #include "aptp_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct WgK {
   int64_t slab_stride, db_stride;
 };
 
+#define APTP_WGRAD_SUB_DEFAULT 2      // measured on the fine-tune step: 38.3 / 37.7 / 38.0 ms with 1 / 2 / 4
 constexpr int PITCH = 72;          // bf16 elements per LDS row (64 + 8: spreads the 4-row transposed blocks over the banks)
 constexpr int XROWS = 104;         // halo rows per buffer: (R+2) * (Wt+2) <= 102
 
@@ -46,11 +48,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* lds_row_q_col_4p, int pl
   return u.v;
 }
 
-template <int TAPS>
+// SUB: 32-pixel sub-steps per barrier.  The 3x3 form stages one halo per 32 pixels (SUB = 1); a 1x1 / linear layer has no halo
+// and only 4 MFMAs per wave and sub-step, so it takes 64 pixels per barrier (SUB = 2; 4 fits too -- 74 KB of LDS -- and measures the same).
+template <int TAPS, int SUB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
-  __shared__ __attribute__((aligned(16))) __bf16 dys[2][32 * PITCH];
-  __shared__ __attribute__((aligned(16))) __bf16 xs[2][(TAPS == 9 ? XROWS : 32) * PITCH];
-  constexpr int XCH = TAPS == 9 ? 4 : 1;           // 16-byte x chunks per thread and step (<= 102 * 8 / 256)
+  static_assert(TAPS == 1 || SUB == 1, "sub-steps only without a halo");
+  __shared__ __attribute__((aligned(16))) __bf16 dys[2][32 * SUB * PITCH];
+  __shared__ __attribute__((aligned(16))) __bf16 xs[2][(TAPS == 9 ? XROWS : 32 * SUB) * PITCH];
+  constexpr int XCH = TAPS == 9 ? 4 : SUB;         // 16-byte x chunks per thread and step (<= 102 * 8 / 256)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wc = wave & 1;
@@ -67,15 +72,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   float dbacc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) dbacc[e] = 0.f;
-  u32x4 rdy, rx[XCH];
-  const int dj = tid >> 3, dch = tid & 7;          // dy tile: row (pixel of the step), 16-byte chunk
+  u32x4 rdy[SUB], rx[XCH];
+  const int dj = tid >> 3, dch = tid & 7;          // dy tile: row (pixel of the sub-step), 16-byte chunk
   const int xrows = TAPS == 9 ? (p.R + 2) * p.hw2 : 32;
   auto load_step = [&](int step) {
-    const int m0 = step * 32;
-    {
-      const int m = m0 + dj, n = n0 + dch * 8;
-      rdy = (u32x4){0u, 0u, 0u, 0u};
-      if (m < p.M && n < p.N) rdy = *reinterpret_cast<const u32x4*>(p.dy + (int64_t)m * p.lddy + n);
+    const int m0 = step * 32 * SUB;
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) {
+      const int m = m0 + sb * 32 + dj, n = n0 + dch * 8;
+      rdy[sb] = (u32x4){0u, 0u, 0u, 0u};
+      if (m < p.M && n < p.N) rdy[sb] = *reinterpret_cast<const u32x4*>(p.dy + (int64_t)m * p.lddy + n);
     }
     if (TAPS == 9) {
       const int b = m0 / p.HW, rem = m0 - b * p.HW;
@@ -92,18 +98,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
         }
       }
     } else {
-      const int m = m0 + dj, c = c0 + dch * 8;
-      rx[0] = (u32x4){0u, 0u, 0u, 0u};
-      if (m < p.M && c < p.C) rx[0] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * p.ldx + c);
+#pragma unroll
+      for (int sb = 0; sb < SUB; ++sb) {
+        const int m = m0 + sb * 32 + dj, c = c0 + dch * 8;
+        rx[sb] = (u32x4){0u, 0u, 0u, 0u};
+        if (m < p.M && c < p.C) rx[sb] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)m * p.ldx + c);
+      }
     }
   };
   auto store_step = [&](int buf) {
-    *reinterpret_cast<u32x4*>(&dys[buf][dj * PITCH + dch * 8]) = rdy;
-    if (want_db) {
-      float f[8];
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(&rdy), f);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dbacc[e] += f[e];
+    for (int sb = 0; sb < SUB; ++sb) {
+      *reinterpret_cast<u32x4*>(&dys[buf][(sb * 32 + dj) * PITCH + dch * 8]) = rdy[sb];
+      if (want_db) {
+        float f[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(&rdy[sb]), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dbacc[e] += f[e];
+      }
     }
     if (TAPS == 9) {
 #pragma unroll
@@ -112,7 +124,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
         if (hr < xrows) *reinterpret_cast<u32x4*>(&xs[buf][hr * PITCH + ch * 8]) = rx[i];
       }
     } else {
-      *reinterpret_cast<u32x4*>(&xs[buf][dj * PITCH + dch * 8]) = rx[0];
+#pragma unroll
+      for (int sb = 0; sb < SUB; ++sb) *reinterpret_cast<u32x4*>(&xs[buf][(sb * 32 + dj) * PITCH + dch * 8]) = rx[sb];
     }
   };
 
@@ -139,18 +152,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
       store_step(buf);
       __syncthreads();
       if (s + 1 < s_end) load_step(s + 1);
-      bf16x8 dfr[2];
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf) dfr[nf] = tr_frag(&dys[buf][d_off + nf * 16], 4 * PITCH);
+      for (int sb = 0; sb < SUB; ++sb) {
+        const int sub_off = sb * 32 * PITCH;
+        bf16x8 dfr[2];
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int shift = TAPS == 9 ? ((t / 3) * p.hw2 + (t % 3)) * PITCH : 0;
+        for (int nf = 0; nf < 2; ++nf) dfr[nf] = tr_frag(&dys[buf][sub_off + d_off + nf * 16], 4 * PITCH);
 #pragma unroll
-        for (int cf = 0; cf < 2; ++cf) {
-          const bf16x8 xf = tr_frag(&xs[buf][x_off + shift + cf * 16], 4 * PITCH);
+        for (int t = 0; t < TAPS; ++t) {
+          const int shift = TAPS == 9 ? ((t / 3) * p.hw2 + (t % 3)) * PITCH : 0;
 #pragma unroll
-          for (int nf = 0; nf < 2; ++nf)
-            acc[t][cf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, dfr[nf], acc[t][cf][nf], 0, 0, 0);
+          for (int cf = 0; cf < 2; ++cf) {
+            const bf16x8 xf = tr_frag(&xs[buf][sub_off + x_off + shift + cf * 16], 4 * PITCH);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+              acc[t][cf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, dfr[nf], acc[t][cf][nf], 0, 0, 0);
+          }
         }
       }
       buf ^= 1;
@@ -222,22 +239,27 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   WgK k;
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dw = p->dw;
   k.B = p->B; k.H = p->H; k.W = p->W; k.C = p->C; k.N = p->N; k.HW = p->H * p->W; k.M = p->B * k.HW;
-  k.nsteps = (k.M + 31) / 32;
+  // sub-steps per barrier of the 1x1 form (APTP_WGRAD_SUB = 1 / 2 / 4 for A/B timing)
+  static const int sub_env = [] { const char* e = getenv("APTP_WGRAD_SUB"); return e ? atoi(e) : 0; }();
+  const int SUB1 = (sub_env == 1 || sub_env == 2 || sub_env == 4) ? sub_env : APTP_WGRAD_SUB_DEFAULT;
+  k.nsteps = p->KH == 3 ? (k.M + 31) / 32 : (k.M + 32 * SUB1 - 1) / (32 * SUB1);
   k.ldw = p->ld_dw ? p->ld_dw : p->C;
   k.db = p->db;
   k.slab_stride = p->slab_stride ? p->slab_stride : (int64_t)p->N * p->KH * p->KW * k.ldw;
   k.db_stride = p->db_stride ? p->db_stride : p->N;
   APTP_CHECK(k.slab_stride >= (int64_t)p->N * p->KH * p->KW * k.ldw && k.slab_stride % 4 == 0 && k.db_stride >= p->N, "conv_wgrad: slab strides");
   APTP_CHECK(k.ldw >= p->C && k.ldw % 4 == 0, "conv_wgrad: ld_dw");
-  k.split = p->split_m > k.nsteps ? k.nsteps : p->split_m;
-  APTP_CHECK(k.split == p->split_m, "conv_wgrad: split_m %d exceeds the %d K-steps", p->split_m, k.nsteps);
+  k.split = p->split_m;                 // (a slice without a barrier step of its own writes zeros: the caller folds split_m slabs)
+  APTP_CHECK(p->split_m <= (k.M + 31) / 32, "conv_wgrad: split_m %d exceeds the %d 32-pixel steps", p->split_m, (k.M + 31) / 32);
   k.tiles_n = (p->N + 63) / 64; k.tiles_c = (p->C + 63) / 64;
   k.Wt = p->W < 32 ? p->W : 32; k.R = p->W < 32 ? 32 / p->W : 1; k.hw2 = k.Wt + 2;
   APTP_CHECK(p->KH == 1 || (k.R + 2) * k.hw2 <= XROWS, "conv_wgrad: halo does not fit");
   const int64_t nblk = (int64_t)k.tiles_n * k.tiles_c * k.split;
   APTP_CHECK(nblk < (1LL << 31), "conv_wgrad: grid too large");
-  if (p->KH == 3) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  if (p->KH == 3) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  else if (SUB1 == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  else if (SUB1 == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
   APTP_LAUNCH_CHECK();
   return APTP_OK;
 }

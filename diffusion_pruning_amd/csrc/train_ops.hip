@@ -81,18 +81,28 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwdK p) {
   }
   if (active) {
     const int64_t row0 = (int64_t)b * k.HW;
-    for (int r = r0 + rl; r < r1; r += k.RPAR) {
+    // two rows per trip: all four 16-byte loads of a (page, row pair) are in flight before the arithmetic
+    for (int r = r0 + rl; r < r1; r += 2 * k.RPAR) {
+      const int rb = r + k.RPAR;
+      const bool two = rb < r1;
 #pragma unroll
       for (int pg = 0; pg < NP; ++pg) {
         const int o = ot + pg * 256;
         if (o < k.CO) {
-          const u32x4 qd = *reinterpret_cast<const u32x4*>(p.dy + (row0 + r) * p.lddy + o * 8);
-          const u32x4 qy = *reinterpret_cast<const u32x4*>(p.y0 + (row0 + r) * p.ldy0 + o * 8);
-          float d[8], y[8], dxv[8];
-          unpack8(qd, d); unpack8(qy, y);
+          u32x4 qd[2], qy[2];
+          qd[0] = *reinterpret_cast<const u32x4*>(p.dy + (row0 + r) * p.lddy + o * 8);
+          qy[0] = *reinterpret_cast<const u32x4*>(p.y0 + (row0 + r) * p.ldy0 + o * 8);
+          qd[1] = two ? *reinterpret_cast<const u32x4*>(p.dy + (row0 + rb) * p.lddy + o * 8) : (u32x4){0u, 0u, 0u, 0u};
+          qy[1] = two ? *reinterpret_cast<const u32x4*>(p.y0 + (row0 + rb) * p.ldy0 + o * 8) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { acc[pg][e] += d[e] * y[e]; dxv[e] = d[e] * gm[pg][e]; }
-          *reinterpret_cast<u32x4*>(p.dx + (row0 + r) * p.lddx + o * 8) = pack8(dxv);
+          for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            float d[8], y[8], dxv[8];
+            unpack8(qd[h], d); unpack8(qy[h], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc[pg][e] += d[e] * y[e]; dxv[e] = d[e] * gm[pg][e]; }
+            *reinterpret_cast<u32x4*>(p.dx + (row0 + (h ? rb : r)) * p.lddx + o * 8) = pack8(dxv);
+          }
         }
       }
     }

@@ -146,6 +146,8 @@ def tune(args, lib, log):
     counters = ops._tile_counters(dev)
     uniq = {}
     for rec in log:
+        if "fn" in rec:                   # aptp_ff_tail etc.: not a conv_gemm launch
+            continue
         p = rec["params"]
         key = ops.tuning_key(p.B * p.Hout * p.Wout, p.N, p.Cin, p.KH * p.KW, p.stride, p.ups, p.act == ACT_GEGLU, p.Cin2 if p.x2 else 0)
         u = uniq.setdefault(key, {"rec": rec, "count": 0})

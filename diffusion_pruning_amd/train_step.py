@@ -667,7 +667,7 @@ class GraphedFineTunerStep(FineTunerStep):
             snr = snr + 1
         return (torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr).float()
 
-    def capture(self, batch: dict, warmup_iters: int = 2, offload_masters: bool = False, _diag: str = ""):
+    def capture(self, batch: dict, warmup_iters: int = 2, offload_masters: bool = False):
         """Build the packed trainable state, ONE HIP graph of teacher forward + student forward + losses + backward for this
         batch geometry, and the one-launch AdamW over the gradients that graph leaves behind."""
         dev = batch["noisy_latents"].device
@@ -692,32 +692,21 @@ class GraphedFineTunerStep(FineTunerStep):
             with torch.no_grad():
                 full_pred = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
             pred = self.student(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
-            if "simpleloss" in _diag:
-                total = pred.float().pow(2).mean()
-                diff = dist_l = blk = total.detach()
-            else:
-                total, diff, dist_l, blk = self._losses(pred, full_pred, st["snr_w"], st["target"])
+            total, diff, dist_l, blk = self._losses(pred, full_pred, st["snr_w"], st["target"])
             total.backward()
             out.update(total=total.detach(), diff=diff, dist=dist_l, blk=blk)
 
-        import os as _os
-        import sys as _sys
-        _tr = (lambda m: print("[ft-capture]", m, file=_sys.stderr, flush=True)) if _os.environ.get("APTP_FT_TRACE") else (lambda m: None)
         # warm-up (allocator, plan caches, autograd's stream anchors) runs forward + backward only: nothing to undo afterwards
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for i in range(warmup_iters):
                 fwd_bwd()
-                _tr(f"warm-up {i} issued")
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        _tr("warm-up done")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             fwd_bwd()
-            _tr("captured body")
-        _tr("capture ended")
         # The optimizer is ONE launch over every trainable tensor and writes the bf16 operands in the same pass
         # (packed_train.PackedAdamW, csrc/optim.hip); its table holds the addresses of the gradients the captured backward
         # left in `.grad`, which every replay re-writes in place.  It runs right behind the graph, followed by the one-launch

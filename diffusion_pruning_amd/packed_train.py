@@ -287,4 +287,16 @@ class PackedAdamW:
         self.trainer.refresh_(shadows_done=True)
 
     def state_dict(self):
+        """step count and both moments, in the order of the trainer's tensors (resume: load_state_dict on an optimizer built
+        over the same expert)"""
         return {"step": self.step_t.clone(), "exp_avg": [m.clone() for m in self.m], "exp_avg_sq": [v.clone() for v in self.v]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        assert len(sd["exp_avg"]) == len(self.m) and len(sd["exp_avg_sq"]) == len(self.v), "PackedAdamW: different tensor list"
+        self.step_t.copy_(sd["step"])
+        for dst, src in zip(self.m, sd["exp_avg"]):
+            assert dst.shape == src.shape
+            dst.copy_(src)                    # in place: the moments' addresses are part of the kernel's table
+        for dst, src in zip(self.v, sd["exp_avg_sq"]):
+            dst.copy_(src)

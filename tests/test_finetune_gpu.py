@@ -225,3 +225,17 @@ def test_one_launch_adamw_matches_torch_adamw(cuda):
             assert float((p - r).abs().max()) <= 1e-6 * float(r.abs().max()) + 1e-7, it
     assert torch.equal(shadows[0], ps[0].detach().to(torch.bfloat16)) and torch.equal(shadows[1], ps[1].detach().to(torch.bfloat16))
     assert float(opt.step_t) == 4.0
+    # resume: a fresh optimizer over the same tensors, loaded with the saved state, takes the same fifth step
+    sd = opt.state_dict()
+    snap = [p.detach().clone() for p in ps]
+    for p in order:
+        p.grad.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(99)).to(cuda))
+    opt.step()
+    after = [p.detach().clone() for p in ps]
+    with torch.no_grad():
+        for p, s0 in zip(ps, snap):
+            p.copy_(s0)
+    opt2 = PackedAdamW(trainer, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    opt2.load_state_dict(sd)
+    opt2.step()
+    assert all(torch.equal(p.detach(), a) for p, a in zip(ps, after)) and float(opt2.step_t) == 5.0

@@ -22,6 +22,20 @@ data-parallel pruning train step (configs[2]/[3]) behind ``--config train``.
     one all-gather) and ONE flat all-reduce of the router gradients (the DDP exchange of trainer.py:922), AdamW.
     Reports steps/s summed over ranks, per-GPU steps/s and the collectives' share of a step.
 
+--config finetune
+    BASELINE configs[4]: the expert fine-tune step (FineTuner.step, trainer.py:1683-1765 -- dense teacher forward, pruned
+    student forward + backward incl. weight gradients, AdamW) on eight distinct seeded architecture codes (keep ratio
+    0.40 .. 0.75, 0-4 depth gates off), ONE EXPERT PER GPU: rank r trains expert (r + --expert-offset) % 8 and the ranks
+    never communicate (scripts/aptp/finetune.py:27-28,40); N = 1 trains expert 3.  The whole step replays from a HIP graph
+    (train_step.GraphedFineTunerStep).  value = steps/s summed over the ranks (each rank's own rate is listed).
+
+The default line (--config infer, one GPU) also carries:
+  sustained       >= 3 s of back-to-back replays of the same graph: steps/s, the slowest / median 100-step window and the
+                  shader clock (sysfs pp_dpm_sclk, sampled by a host thread while the replays run) beside it.
+  extra_configs   BASELINE configs[2] (train) and configs[4] (finetune, expert 3) measured after the headline in this same
+                  process: steps/s, ms/step, graph nodes (launches) per step, the conv_gemm family's MFMA roofline
+                  fraction inside that step, peak memory.
+
 Prints ONE JSON line (see the task contract) with extra objects:
   roofline        MFMA roofline of the dominant kernel family (conv_gemm*: implicit-GEMM conv/linear): achieved =
                   algorithmic FLOPs of all its launches in one forward / their measured device time (HIP events on the
@@ -56,7 +70,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("infer", "train"), default="infer")
+    ap.add_argument("--config", choices=("infer", "train", "finetune"), default="infer")
+    ap.add_argument("--expert-offset", type=int, default=None, help="(finetune) rank r trains expert (r + offset) %% 8; default 3 at N = 1, else 0")
+    ap.add_argument("--no-extra-configs", action="store_true", help="(infer) skip the train / finetune measurements that follow the headline")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0, help="(infer) length of the sustained-replay leg; 0 = off")
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--dense", action="store_true", help="(infer) mask == 1 instead of the fixed 50 %% mask")
@@ -72,6 +89,8 @@ def parse_args(argv=None):
         args.steps = 50 if args.config == "infer" else 10
     if args.warmup is None:
         args.warmup = 5 if args.config == "infer" else 3
+    if args.expert_offset is None:
+        args.expert_offset = 3 if args.gpus == 1 else 0
     return args
 
 
@@ -181,6 +200,7 @@ class Rank:
         for _ in range(steps):
             run()
         self.sync()
+        self.last_local_elapsed = time.perf_counter() - t0        # this rank's own K steps (before the closing barrier)
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0)
 
@@ -271,6 +291,9 @@ def run_infer(R: Rank):
             assert torch.isfinite(gout).all() and d <= 1e-2 * float(out.float().abs().max()), f"graph replay differs from eager: {d}"
         ms_per_step = elapsed / args.steps * 1e3
         value = R.world * args.steps / elapsed
+        sustained = None
+        if R.rank == 0 and not R.cpu and not args.no_extras and gout is not None and R.world == 1 and args.sustain_seconds > 0:
+            sustained = measure_sustained(run, args.sustain_seconds, value, R.local_rank)
         if R.rank == 0 and not R.cpu and not args.no_extras:
             # (at N > 1 the other ranks wait for these legs in the final barrier: only the short ones run there)
             roofline = measure_roofline(ops, step, dev, per_tile=R.world == 1)
@@ -282,6 +305,33 @@ def run_infer(R: Rank):
             roofline_gn = measure_gn_roofline(ops, step, dev)
             if R.world == 1 and not args.no_cpu_baseline:
                 cpu_baseline = measure_cpu_baseline(model, args.dense)
+    extra_configs = None
+    if R.rank == 0 and R.world == 1 and not R.cpu and not args.no_extras and not args.no_extra_configs and L == 64:
+        # BASELINE configs[2] and configs[4] in the same record (the driver runs only this default command): measured after
+        # the headline, with the inference model released first
+        del model, run
+        if gout is not None:
+            del graph, gout
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        extra_configs = {}
+        for name, fn in (("train", run_train), ("finetune", run_finetune)):
+            t0 = time.perf_counter()
+            try:
+                torch.cuda.reset_peak_memory_stats()
+                rec = fn(R, steps=20, warmup=3)
+                extra_configs[name] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config",
+                                                           "graph_nodes_per_step", "family_roofline", "max_mem_GiB", "loss") if k in rec}
+                for k in ("launches_per_step", "launches_per_step_in_graphs", "collectives", "experts"):
+                    if k in rec:
+                        extra_configs[name][k] = rec[k]
+            except Exception as e:  # noqa: BLE001   (never lose the headline line to an extra)
+                import traceback
+                extra_configs[name] = {"error": repr(e), "where": traceback.format_exc()[-600:]}
+            extra_configs[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+            gc.collect()
+            torch.cuda.empty_cache()
     if R.rank != 0:
         return None
     what = "mask=1" if args.dense else "fixed 50% mask (gated semantics)"
@@ -295,13 +345,16 @@ def run_infer(R: Rank):
                    "global_batch": B * R.world, "parallelism": f"replicas x{R.world} (no data-path collective)"},
         "per_gpu_steps_per_s": round(value / R.world, 3),
         "roofline": roofline, "roofline_groupnorm": roofline_gn, "cpu_baseline": cpu_baseline,
+        "sustained": sustained, "extra_configs": extra_configs,
     }
     return line
 
 
-def run_train(R: Rank):
+def run_train(R: Rank, steps=None, warmup=None, extras: bool = True):
     """BASELINE configs[2] (N = 1) / configs[3] (N > 1): the APTP pruning train step, data-parallel."""
     torch, args, dev = R.torch, R.args, R.dev
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     from diffusion_pruning_amd import dist_utils
     from diffusion_pruning_amd.hypernet import HyperStructure
     from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
@@ -329,18 +382,28 @@ def run_train(R: Rank):
     opt = torch.optim.AdamW(step.trainable_parameters(), lr=2e-4)
     xdim = 1024 if not R.cpu else unet.real.config["cross_attention_dim"]
     batch = synthetic_batch(args.batch, latent, dev, seed=1234 + R.rank, cross_dim=xdim, text_dim=text_dim)   # rank-local shard
+    nodes = fam_log = None
     if graphed:
-        step.capture(batch)
+        from diffusion_pruning_amd import graph_utils, ops
+        graph_utils.KEEP_GRAPHS = True
+        ops.LAUNCH_LOG = [] if (extras and R.rank == 0) else None
+        try:
+            step.capture(batch)
+        finally:
+            graph_utils.KEEP_GRAPHS = False
+            ops.LAUNCH_LOG = None
+        nodes, fam_log = step.graph_nodes(), step._cap.get("launch_log")
+        torch.cuda.reset_peak_memory_stats()
     timer = dist_utils.CollectiveTimer()
     out = {}
 
     def run():
         out["o"] = step.train_step(opt, batch, pretrain=R.cpu)
 
-    elapsed = R.timed(run, args.steps, args.warmup)
+    elapsed = R.timed(run, steps, warmup)
     # collective share: a few more steps with the device-side stopwatch around every collective of the step
     dist_utils.COLLECTIVE_TIMER = timer
-    n_probe = min(args.steps, 5)
+    n_probe = min(steps, 5)
     for _ in range(n_probe):
         run()
     R.sync()
@@ -355,16 +418,20 @@ def run_train(R: Rank):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         assert torch.equal(lo, hi), "router replicas diverged across ranks"
     assert torch.isfinite(flat).all()
-    ms_per_step = elapsed / args.steps * 1e3
-    value = R.world * args.steps / elapsed
+    ms_per_step = elapsed / steps * 1e3
+    value = R.world * steps / elapsed
     if R.rank != 0:
         return None
     o = out["o"]
     mem = None if R.cpu else round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+    fam = None
+    if graphed and extras and fam_log:
+        from diffusion_pruning_amd import ops
+        fam = family_roofline(ops, fam_log)
     return {
         "metric": "pruning-train-steps/s (APTP Pruner.step: router + dense teacher fwd + soft-masked student fwd/bwd, SD-2.1, "
                   "64x64 latents, bs=4 per GPU; summed over data-parallel ranks)",
-        "value": round(value, 3), "unit": "steps/s", "n_gpus": R.n_seen, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": R.n_seen, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[3]" if R.world > 1 else "BASELINE configs[2]") +
@@ -373,12 +440,132 @@ def run_train(R: Rank):
                    "global_batch": args.batch * R.world,
                    "parallelism": f"dp{R.world}: frozen U-Net replicas; per step 1 fused all-gather [B,768+1620], 1 all-gather of "
                                   "Sinkhorn scores [B,8], 1 flat fp32 all-reduce of 1.26 M router gradients"},
-        "per_gpu_steps_per_s": round(value / R.world, 3), "global_steps_per_s": round(args.steps / elapsed, 3),
+        "per_gpu_steps_per_s": round(value / R.world, 3), "global_steps_per_s": round(steps / elapsed, 3),
         "samples_per_s": round(value * args.batch, 2),
+        "graph_nodes_per_step": nodes,
+        "launches_per_step_in_graphs": None if not nodes or None in nodes.values() else sum(nodes.values()),
+        "family_roofline": fam,
         "collectives": {"ms_per_step": round(coll_ms, 4), "share_of_step": round(coll_ms / ms_per_step, 5), "spans_ms": spans,
                         "how": "HIP events on the launch stream around each collective, mean of %d steps" % n_probe},
         "loss": float(o["loss"].detach()), "resource_ratio": float(o["resource_ratio"]), "max_mem_GiB": mem,
         "replicas_identical_after_run": True,
+    }
+
+
+def expert_mask(structure, expert: int, device):
+    """architecture code of benchmark expert 0..7 (BASELINE configs[4] "8 distinct arch codes, mixed width + depth pruning"):
+    keep ratio 0.40 + 0.05 * expert of every width gate (seeded random positions), expert % 5 depth gates off"""
+    import torch
+    g = torch.Generator().manual_seed(1000 + expert)
+    keep = 0.4 + 0.05 * expert
+    width = []
+    for sub in structure["width"]:
+        for w in sub:
+            m = torch.zeros(1, w)
+            m[0, torch.randperm(w, generator=g)[:max(1, int(keep * w))]] = 0.9
+            width.append(m.to(device))
+    nd = sum(d for sub in structure["depth"] for d in sub)
+    depth = [torch.full((1,), 0.9, device=device) for _ in range(nd)]
+    for i in torch.randperm(nd, generator=g)[:expert % 5].tolist():
+        depth[i] = torch.zeros(1, device=device)
+    return {"width": width, "depth": depth}
+
+
+def family_roofline(ops, launch_log):
+    """MFMA roofline of the conv_gemm family INSIDE a captured training step: the launches recorded while the step was
+    captured (forward and data-gradient contractions; weight gradients are a different kernel), replayed from a graph of
+    their own between HIP events"""
+    import torch
+    if not launch_log:
+        return None
+    lib = ops._lib.load()
+    stream = torch.cuda.Stream()
+
+    def fn():
+        s = torch.cuda.current_stream().cuda_stream
+        for rec in launch_log:
+            rc = getattr(lib, rec.get("fn", "aptp_conv_gemm"))(ctypes.byref(rec["params"]), s)
+            assert rc == 0
+    ms = _time_graph(torch, stream, fn, reps=5)
+    flops = sum(r["flops"] for r in launch_log)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "conv_gemm family (forward + data-gradient contractions of one step)", "launches": len(launch_log),
+            "family_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
+            "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+
+
+def run_finetune(R: Rank, steps=None, warmup=None, extras: bool = True):
+    """BASELINE configs[4]: expert fine-tune, one expert per GPU, no collective on the data path."""
+    torch, args, dev = R.torch, R.args, R.dev
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    expert = (R.rank + args.expert_offset) % 8
+    if R.cpu:
+        step, batch, n_train, keep = _dryrun_install().install_finetune(expert, args.batch)
+        nodes = fam = None
+    else:
+        from diffusion_pruning_amd import graph_utils, ops
+        from diffusion_pruning_amd.train_step import GraphedFineTunerStep, synthetic_batch
+        from diffusion_pruning_amd.unet import UNet2DConditionModelGated, UNet2DConditionModelPruned
+        teacher = UNet2DConditionModelGated().init_synthetic(seed=0)
+        student = UNet2DConditionModelPruned()
+        student.load_state_dict(teacher.state_dict())
+        teacher.to(dev).freeze()
+        st = teacher.get_structure()
+        teacher.set_structure(ones_mask(st, dev))
+        student.to(dev)
+        student.prune(expert_mask(st, expert, dev))
+        batch = synthetic_batch(args.batch, args.latent, dev, seed=1234 + R.rank)
+        step = GraphedFineTunerStep(student, teacher, lr=1e-5)
+        graph_utils.KEEP_GRAPHS = True
+        ops.LAUNCH_LOG = [] if (extras and R.rank == 0) else None
+        try:
+            step.capture(batch, offload_masters=True)
+        finally:
+            graph_utils.KEEP_GRAPHS = False
+            ops.LAUNCH_LOG = None
+        n_train, keep = step.trainer.n_trainable(), 0.4 + 0.05 * expert
+        nodes = step.graph_nodes()
+        fam = None
+    out = {}
+
+    def run():
+        out["o"] = step.train_step(None, batch)
+
+    torch.cuda.reset_peak_memory_stats() if not R.cpu else None
+    elapsed = R.timed(run, steps, warmup)
+    loss = float(out["o"]["loss"])
+    assert loss == loss, "fine-tune loss is NaN"
+    my_rate = steps / R.last_local_elapsed                      # this rank's own rate; `elapsed` is the MAX over ranks
+    mem = None if R.cpu else round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+    if not R.cpu and extras and R.rank == 0:
+        from diffusion_pruning_amd import ops
+        fam = family_roofline(ops, step._cap.get("launch_log"))
+    # every rank's expert / parameter count / loss, gathered for the record (not on the data path)
+    per_rank = [{"rank": R.rank, "expert": expert, "keep_ratio": round(keep, 2), "trainable_parameters": n_train, "loss": loss,
+                 "steps_per_s": round(my_rate, 3), "max_mem_GiB": mem}]
+    if R.dist:
+        gathered = [None] * R.world
+        torch.distributed.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    if R.rank != 0:
+        return None
+    ms_per_step = elapsed / steps * 1e3
+    value = R.world * steps / elapsed
+    return {
+        "metric": "expert-finetune-steps/s (APTP FineTuner.step: dense teacher fwd + pruned student fwd/bwd incl. weight gradients + "
+                  "AdamW, SD-2.1, 64x64 latents, bs=4 per GPU; one expert per GPU, summed over ranks)",
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": R.n_seen, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4]: expert fine-tune, 8 seeded architecture codes (keep 0.40-0.75, 0-4 depth gates "
+                               f"off), rank r trains expert (r + {args.expert_offset}) % 8, bs={args.batch}/GPU, whole step replayed from "
+                               "a HIP graph + one-launch AdamW",
+                   "global_batch": args.batch * R.world,
+                   "parallelism": f"experts x{R.world}: one expert per GPU, no collective on the data path (finetune.py:27-28)"},
+        "per_gpu_steps_per_s": round(value / R.world, 3), "experts": per_rank, "graph_nodes_per_step": nodes,
+        "launches_per_step": None if not nodes or None in nodes.values() else sum(nodes.values()) + 3,
+        "family_roofline": fam, "max_mem_GiB": mem, "loss": loss,
     }
 
 
@@ -401,6 +588,85 @@ def _time_graph(torch, stream, fn, reps=10):
         e1.record(stream)
         stream.synchronize()
         return e0.elapsed_time(e1) / reps
+
+
+def _sclk_reader(local_rank: int):
+    """current shader clock (MHz) from sysfs pp_dpm_sclk of the card this rank runs on -- a plain file read, no GPU API (None
+    when the file is not there or not readable).  The in-kernel clock of an MFMA-dense loop reads up to ~10 % below it
+    (MI355X_MICROARCH.md, DVFS give-back item 6): the figure is a companion of the rate, not a calibration."""
+    import glob
+    import re
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    # visible-device order is not the card order on a shared host: take the card whose file shows the HIGHEST current level
+    # while this process loads its GPU (chosen at the first sample)
+    state = {"path": None}
+
+    def cur(path):
+        try:
+            with open(path) as f:
+                for ln in f:
+                    if "*" in ln:
+                        m = re.search(r"(\d+)\s*Mhz", ln, re.I)
+                        return int(m.group(1)) if m else None
+        except OSError:
+            return None
+        return None
+
+    def read():
+        if state["path"] is None:
+            best = max(((cur(p) or 0, p) for p in cards), default=(0, None))
+            state["path"] = best[1]
+            return best[0] or None
+        return cur(state["path"])
+    return read
+
+
+def measure_sustained(replay, seconds: float, headline_value: float, local_rank: int):
+    """>= `seconds` of back-to-back replays of the captured forward: steps/s over the whole span, per window of 100 steps
+    (HIP events on the replay stream: slowest and median window), and the shader clock sampled by a host thread meanwhile."""
+    import threading
+    import torch
+    n_win = max(3, int(seconds * max(headline_value, 1.0) / 100.0) + 1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
+    reader = _sclk_reader(local_rank)
+    clocks, stop = [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            v = reader()
+            if v:
+                clocks.append(v)
+            stop.wait(0.05)
+    th = None
+    if reader is not None:
+        th = threading.Thread(target=sample, daemon=True)
+    for _ in range(100):
+        replay()
+    torch.cuda.synchronize()
+    if th is not None:
+        th.start()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for w in range(n_win):
+        for _ in range(100):
+            replay()
+        ev[w + 1].record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    stop.set()
+    if th is not None:
+        th.join(timeout=1.0)
+    wins = sorted(100.0 / (ev[i].elapsed_time(ev[i + 1]) * 1e-3) for i in range(n_win))
+    sps = 100.0 * n_win / wall
+    out = {"seconds": round(wall, 2), "steps": 100 * n_win, "steps_per_s": round(sps, 2),
+           "window_100_steps": {"min_steps_per_s": round(wins[0], 2), "median_steps_per_s": round(wins[len(wins) // 2], 2),
+                                "max_steps_per_s": round(wins[-1], 2)},
+           "vs_headline": round(sps / headline_value, 4),
+           "sclk_mhz": None if not clocks else {"min": min(clocks), "median": sorted(clocks)[len(clocks) // 2], "max": max(clocks),
+                                                "samples": len(clocks), "source": "sysfs pp_dpm_sclk, 50 ms host-thread samples during the run"}}
+    return out
 
 
 def measure_roofline(ops, step, dev, per_tile: bool = True):
@@ -548,7 +814,7 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))
     R = Rank(args)
-    line = run_train(R) if args.config == "train" else run_infer(R)
+    line = {"train": run_train, "finetune": run_finetune, "infer": run_infer}[args.config](R)
     if line is not None:
         if R.cpu:
             line["data"] = "DRYRUN on CPU with emulated ops and a tiny model: exercises launch/rendezvous/reporting only, NOT a measurement"

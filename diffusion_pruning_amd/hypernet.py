@@ -65,6 +65,12 @@ class HyperStructure(nn.Module):
             elif "bias" in name:
                 nn.init.zeros_(param)
 
+    def print_param_stats(self):
+        """hypernet.py:81-84: mean / std of every weight tensor"""
+        for name, param in self.named_parameters():
+            if "weight" in name:
+                print(f"{name}: {param.mean()}, {param.std()}")
+
     def forward(self, x):
         if self.single_arch_param:
             return self.arch          # one shared architecture for the whole batch (hypernet.py:66-68)
@@ -98,8 +104,13 @@ class HyperStructure(nn.Module):
             ok = True
             for k, ps in kinds.items():
                 f = flat[k]
-                last = f.shape[0] - ps[-1].shape[0]
-                ok = ok and ps[0].data_ptr() == f.data_ptr() and ps[-1].data_ptr() == f[last:].data_ptr()
+                # EVERY head must still alias its rows of the flat buffer (a partial load or a manual re-initialisation can
+                # re-assign one head's .data in the middle): 71 integer compares per kind
+                base, row_bytes, off = f.data_ptr(), f.stride(0) * f.element_size(), 0
+                for q in ps:
+                    ok = ok and q.data_ptr() == base + off * row_bytes and q.device == f.device and q.dtype == f.dtype
+                    off += q.shape[0]
+                ok = ok and off == f.shape[0]
             if ok:
                 return flat, kinds
         flat = {}

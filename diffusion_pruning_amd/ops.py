@@ -214,6 +214,7 @@ TUNING = _load_tuning()
 TUNING_NEAREST = os.environ.get("APTP_TUNING_NEAREST", "1") != "0"
 TUNING_MAX_DIST = 2.0
 _HALO_TILES = (43, 44)
+SK_TILE_FIRST = 64          # APTP_TILE_SK_*: persistent stream-K macro-tiles (csrc/conv_gemm_sk.hip)
 _tuning_index = None
 _tuning_near_cache = {}
 
@@ -548,7 +549,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     explicit_split = split_k is not None
     if split_k is None and tile == 0:
         tuned = tuning_lookup(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2)
-        if tuned is not None and tuned["tile"] >= 7 and max(pw.cin_pad, pw.cin2_pad) > 4032:
+        if tuned is not None and tuned["tile"] >= 7 and max(pw.cin_pad, pw.cin2_pad) > (32704 if tuned["tile"] >= SK_TILE_FIRST else 4032):
             tuned = None                   # the LDS-DMA tiles address at most 4032 channels per tap (a neighbour's tile may be one)
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
@@ -578,12 +579,16 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             and (in_kernel or p.split_k <= 2)
         if rowstats or want_cols:
             in_kernel = True
-        if SPLITK_IN_KERNEL and in_kernel and lib.aptp_conv_gemm_tiles(ctypes.byref(p)) <= _N_COUNTERS:
+        sk_tile = p.tile >= SK_TILE_FIRST     # persistent stream-K tiles: partial tiles are always combined in-kernel
+        if (SPLITK_IN_KERNEL or sk_tile) and (in_kernel or sk_tile) and lib.aptp_conv_gemm_tiles(ctypes.byref(p)) <= _N_COUNTERS:
             cnt = _tile_counters(x.device)
             if cnt is not None:
                 p.tile_counters = cnt.data_ptr()
-        ws = _workspace(lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(p)), x.device)
-        p.workspace = ws.data_ptr()
+        if sk_tile and cnt is None:
+            p.split_k = 1                     # no counters at hand (pool exhausted / first use under capture): whole tiles only
+        else:
+            ws = _workspace(lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(p)), x.device)
+            p.workspace = ws.data_ptr()
     stats = None
     if rowstats and (p.split_k == 1 or cnt is not None):
         slots = lib.aptp_conv_gemm_rowstat_slots(ctypes.byref(p))

@@ -176,6 +176,22 @@ class PackedTrainer:
             ps += [a.Pg, a.Pb]
         return ps
 
+    def named_parameters(self):
+        """(stable name, packed tensor) pairs: the diffusers name of the parameter an entry was packed from + the kind of the
+        packed tensor, so optimizer state can be matched by NAME on resume (the registry's own order is the first-run order
+        of the modules)"""
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        out = []
+        for e in self.gemms.values():
+            base = names.get(id(e.weight), f"<unnamed weight {tuple(e.weight.shape)}>")
+            out.append((base + "::packed", e.P))
+            if e.Pb is not None:
+                out.append((base + "::packed_bias", e.Pb))
+        for a in self.affines.values():
+            base = names.get(id(a.gamma_p), f"<unnamed affine {tuple(a.gamma_p.shape)}>")
+            out += [(base + "::gamma", a.Pg), (base + "::beta", a.Pb)]
+        return out
+
     def n_trainable(self) -> int:
         return sum(p.numel() for p in self.parameters())
 
@@ -242,6 +258,8 @@ class PackedAdamW:
         dev = entries[0][0].device
         self.entries = entries
         self.params = [p for p, _ in entries]
+        by_id = {id(p): n for n, p in trainer.named_parameters()} if hasattr(trainer, "named_parameters") else {}
+        self.names = [by_id.get(id(p), f"#{i}") for i, p in enumerate(self.params)]
         self.m = [torch.zeros_like(p.data) for p in self.params]
         self.v = [torch.zeros_like(p.data) for p in self.params]
         self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
@@ -258,7 +276,8 @@ class PackedAdamW:
         starts = [0]
         for i, ((p, sh), m, v) in enumerate(zip(self.entries, self.m, self.v)):
             g = p.grad
-            assert g is not None and g.is_contiguous() and p.data.is_contiguous() and g.dtype == torch.float32 and p.dtype == torch.float32
+            assert g is not None, f"PackedAdamW.rebind_: {self.names[i]} has no gradient (every tensor of the table needs one)"
+            assert g.is_contiguous() and p.data.is_contiguous() and g.dtype == torch.float32 and p.dtype == torch.float32
             assert p.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and m.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
             it = items[i]
             it.p, it.g, it.m, it.v, it.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
@@ -287,16 +306,30 @@ class PackedAdamW:
         self.trainer.refresh_(shadows_done=True)
 
     def state_dict(self):
-        """step count and both moments, in the order of the trainer's tensors (resume: load_state_dict on an optimizer built
-        over the same expert)"""
-        return {"step": self.step_t.clone(), "exp_avg": [m.clone() for m in self.m], "exp_avg_sq": [v.clone() for v in self.v]}
+        """step count and both moments, keyed by the stable names of PackedTrainer.named_parameters() (resume:
+        load_state_dict on an optimizer built over the same expert, whatever order its modules first ran in)"""
+        return {"step": self.step_t.clone(), "names": list(self.names),
+                "exp_avg": [m.clone() for m in self.m], "exp_avg_sq": [v.clone() for v in self.v]}
 
     @torch.no_grad()
     def load_state_dict(self, sd):
-        assert len(sd["exp_avg"]) == len(self.m) and len(sd["exp_avg_sq"]) == len(self.v), "PackedAdamW: different tensor list"
+        assert len(sd["exp_avg"]) == len(sd["exp_avg_sq"]), "PackedAdamW: malformed state"
+        names = sd.get("names")
+        if names is None:                       # (states written before entries were named: positional)
+            assert len(sd["exp_avg"]) == len(self.m), "PackedAdamW: different tensor list"
+            order = list(range(len(self.m)))
+        else:
+            pos = {n: i for i, n in enumerate(names)}
+            missing = [n for n in self.names if n not in pos]
+            assert not missing and len(pos) == len(names) == len(self.names), \
+                f"PackedAdamW: the saved state belongs to another expert / tensor list (missing {missing[:3]}, " \
+                f"{len(names)} saved vs {len(self.names)} here)"
+            order = [pos[n] for n in self.names]
+        for i, j in enumerate(order):
+            ma, va = sd["exp_avg"][j], sd["exp_avg_sq"][j]
+            assert self.m[i].shape == ma.shape and self.v[i].shape == va.shape, \
+                f"PackedAdamW: {self.names[i]}: saved moments {tuple(ma.shape)} / {tuple(va.shape)} vs {tuple(self.m[i].shape)}"
         self.step_t.copy_(sd["step"])
-        for dst, src in zip(self.m, sd["exp_avg"]):
-            assert dst.shape == src.shape
-            dst.copy_(src)                    # in place: the moments' addresses are part of the kernel's table
-        for dst, src in zip(self.v, sd["exp_avg_sq"]):
-            dst.copy_(src)
+        for i, j in enumerate(order):
+            self.m[i].copy_(sd["exp_avg"][j])    # in place: the moments' addresses are part of the kernel's table
+            self.v[i].copy_(sd["exp_avg_sq"][j])

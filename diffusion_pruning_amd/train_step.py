@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import dist_utils
 from . import autograd as AG
+from .graph_utils import new_graph, node_count
 from . import ops
 from .dist_utils import _rank, _span, _world
 from .losses import ContrastiveLoss, ResourceLoss, compute_snr
@@ -106,9 +107,17 @@ class BucketedGradReducer:
     on the 7 x 153 GB/s links; the fp32 master gradient receives the mean), and buckets follow REVERSE parameter
     registration order, which is the order the backward produces them in.  Works on any backend (gloo in the CPU tests)."""
 
-    def __init__(self, params, bucket_bytes: int = 64 << 20, wire_dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, params, bucket_bytes: int = 64 << 20, wire_dtype: torch.dtype = torch.bfloat16,
+                 mode: str = "all_reduce", hooks: bool = True):
+        """mode "all_reduce": one all-reduce per bucket.  mode "rs_ag": reduce-scatter + all-gather per bucket -- on the
+        fully connected xGMI mesh of an MI355X node each of the two is ONE direct exchange between every pair of GPUs
+        ((n-1)/n of the payload over 7 links at once), where a ring all-reduce is 2(n-1) dependent per-link steps (SURVEY
+        5.8: 2.8 ms against 39.6 ms for the 1.7 GB of bf16 gradients); the all-gathers of all buckets are issued together
+        after the backward.  hooks=False: no per-parameter hooks (a captured backward cannot run them): the caller
+        exchanges everything with ``exchange_all()`` once the gradients are in place."""
+        assert mode in ("all_reduce", "rs_ag"), mode
         self.params = [p for p in params if p.requires_grad]
-        self.wire_dtype = wire_dtype
+        self.wire_dtype, self.mode = wire_dtype, mode
         self.buckets: List[List[torch.nn.Parameter]] = []
         esz = torch.empty((), dtype=wire_dtype).element_size()
         cur, cur_bytes = [], 0
@@ -123,9 +132,10 @@ class BucketedGradReducer:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._shard: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self._pending = [0] * len(self.buckets)
         self._work: List = []
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if hooks else []
         self.reset()
 
     def reset(self):
@@ -144,13 +154,16 @@ class BucketedGradReducer:
             self._launch(i)
 
     def _launch(self, i):
-        if _world() == 1:
+        world = _world()
+        if world == 1:
             return
         ps = self.buckets[i]
         n = sum(p.numel() for p in ps)
+        npad = (n + world - 1) // world * world          # (reduce-scatter needs equal shards; the padding is exchanged as zeros)
         flat = self._flat[i]
-        if flat is None or flat.device != ps[0].device:
-            flat = self._flat[i] = torch.empty(n, dtype=self.wire_dtype, device=ps[0].device)
+        if flat is None or flat.device != ps[0].device or flat.numel() != npad:
+            flat = self._flat[i] = torch.zeros(npad, dtype=self.wire_dtype, device=ps[0].device)
+            self._shard[i] = torch.empty(npad // world, dtype=self.wire_dtype, device=ps[0].device)
         off = 0
         for p in ps:
             k = p.numel()
@@ -160,7 +173,16 @@ class BucketedGradReducer:
             else:
                 flat[off:off + k].copy_(g.reshape(-1))
             off += k
-        self._work.append((i, dist.all_reduce(flat, async_op=True)))
+        self._pending[i] = 0
+        if self.mode == "rs_ag":
+            self._work.append((i, dist.reduce_scatter_tensor(self._shard[i], flat, async_op=True)))
+        else:
+            self._work.append((i, dist.all_reduce(flat, async_op=True)))
+
+    def exchange_all(self):
+        """launch every bucket now and finish (hooks=False: gradients written by a replayed HIP graph)"""
+        self.reset()
+        return self.finish()
 
     def finish(self):
         """Wait for every bucket, write the mean back into .grad (buckets whose parameters received no gradient this
@@ -172,6 +194,13 @@ class BucketedGradReducer:
         for i, left in enumerate(self._pending):
             if left > 0:
                 self._launch(i)
+        if self.mode == "rs_ag":
+            # every shard is reduced once its reduce-scatter is done; the gathers of all buckets then go out back to back
+            gathers = []
+            for i, work in self._work:
+                work.wait()
+                gathers.append((i, dist.all_gather_into_tensor(self._flat[i], self._shard[i], async_op=True)))
+            self._work = gathers
         inv = 1.0 / world
         for i, work in self._work:
             work.wait()
@@ -438,21 +467,32 @@ class GraphedPrunerStep(PrunerStep):
         # on the side stream since the batch arrived; the loss + backward graph joins the two.  Graphs that replay
         # concurrently must not share a memory pool (a pool hands one capture's freed scratch to the next capture, which is
         # only safe when replays are serialised in capture order): the teacher has its own, the two student graphs share one.
+        log0 = None if ops.LAUNCH_LOG is None else len(ops.LAUNCH_LOG)     # (bench.py: the contractions of ONE captured step)
         self.unet.set_structure({"width": list(full["width"]), "depth": list(full["depth"])})
-        g_teacher = torch.cuda.CUDAGraph()
+        g_teacher = new_graph()
         with torch.cuda.graph(g_teacher):
             full_pred, teacher_acts = teacher()
         self.unet.set_structure({"width": list(gw), "depth": list(gd)})
-        g_student = torch.cuda.CUDAGraph()
+        g_student = new_graph()
         with torch.cuda.graph(g_student):
             pred, acts = student_fwd()
-        g_student_bwd = torch.cuda.CUDAGraph()
+        g_student_bwd = new_graph()
         with torch.cuda.graph(g_student_bwd, pool=g_student.pool()):
             loss, dist, blk, grad = student_bwd(pred, acts, full_pred, teacher_acts)
         # (everything a captured kernel reads must outlive the graphs: `inv` is an operand of the gather that ends g_student_bwd)
         self._cap = dict(st=st, ga=ga, install_code=install_code, perm=perm, inv=inv, full=full, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
-                         loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs)
+                         loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs,
+                         launch_log=None if log0 is None else ops.LAUNCH_LOG[log0:])
         return self
+
+    def graph_nodes(self):
+        """nodes (kernel launches + torch's few memcpy / memset nodes) of the three captured graphs, when they were kept
+        (graph_utils.KEEP_GRAPHS): {"teacher", "student_fwd", "student_bwd"}"""
+        cap = self._cap
+        if cap is None:
+            return None
+        return {"teacher": node_count(cap["g_teacher"]), "student_fwd": node_count(cap["g_student"]),
+                "student_bwd": node_count(cap["g_student_bwd"])}
 
     # ---- one step -------------------------------------------------------------------------------------------------------
     def step(self, noisy_latents, timesteps, encoder_hidden_states, text_embeddings, target, pretrain: bool = False):
@@ -559,11 +599,12 @@ class FineTunerStep:
     expert on several GPUs with BucketedGradReducer."""
 
     def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None,
-                 data_parallel: bool = False, bucket_bytes: int = 64 << 20):
+                 data_parallel: bool = False, bucket_bytes: int = 64 << 20, reduce_mode: str = "all_reduce"):
         self.student, self.teacher = student, teacher
         # data_parallel: ONE expert trained on several GPUs (SURVEY C2): bf16 gradient buckets all-reduced while the
         # backward is still running; the default is the reference's "one expert per GPU", which never communicates
-        self.reducer = BucketedGradReducer([p for p in student.parameters() if p.requires_grad], bucket_bytes) \
+        self._dp, self._bucket_bytes, self._reduce_mode, self._reducer_packed = data_parallel, bucket_bytes, reduce_mode, False
+        self.reducer = BucketedGradReducer([p for p in student.parameters() if p.requires_grad], bucket_bytes, mode=reduce_mode) \
             if data_parallel else None
         self.cfg = cfg or FinetuneLossConfig()
         self.schedule = schedule or NoiseSchedule()
@@ -607,7 +648,19 @@ class FineTunerStep:
         return {"loss": loss, "diff_loss": diff_loss, "distillation_loss": distillation_loss.detach(),
                 "block_loss": block_loss.detach()}
 
+    def _packed_reducer(self):
+        """Under a PackedTrainer the gradients the optimizer consumes are those of the PACKED tensors (the diffusers-layout
+        parameters receive none): the data-parallel exchange must run over them, or the ranks silently diverge."""
+        pk = self.student.__dict__.get("_pk")
+        if self._dp and pk is not None and not self._reducer_packed:
+            assert pk.parameters(), "FineTunerStep(data_parallel=True): call PackedTrainer.materialize() before the first step"
+            if self.reducer is not None:
+                self.reducer.remove()
+            self.reducer = BucketedGradReducer(pk.parameters(), self._bucket_bytes, mode=self._reduce_mode)
+            self._reducer_packed = True
+
     def train_step(self, optimizer, batch: dict):
+        self._packed_reducer()
         optimizer.zero_grad(set_to_none=True)
         out = self.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"], batch["target"])
         out["loss"].backward()
@@ -632,8 +685,13 @@ class GraphedFineTunerStep(FineTunerStep):
     Same numbers as FineTunerStep on packed masters with torch.optim.AdamW (tests/test_finetune_gpu.py)."""
 
     def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None,
-                 lr: float = 1e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8):
+                 lr: float = 1e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
+                 data_parallel: bool = False, bucket_bytes: int = 64 << 20, reduce_mode: str = "rs_ag"):
         super().__init__(student, teacher, cfg, schedule)
+        # data_parallel (one expert on several GPUs, SURVEY C2): the replayed graph leaves this rank's gradients in the
+        # packed tensors' .grad; they are averaged over the ranks in buckets (no hooks: nothing of a replay runs on the
+        # host) between the replay and the one-launch AdamW
+        self._dp_graphed, self._bucket_bytes, self._reduce_mode = data_parallel, bucket_bytes, reduce_mode
         from .packed_train import PackedTrainer
         self.trainer = PackedTrainer(student).attach()
         self.opt_kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
@@ -704,9 +762,11 @@ class GraphedFineTunerStep(FineTunerStep):
                 fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        log0 = None if ops.LAUNCH_LOG is None else len(ops.LAUNCH_LOG)     # (bench.py: the contractions of ONE captured step)
+        graph = new_graph()
         with torch.cuda.graph(graph):
             fwd_bwd()
+        launch_log = None if log0 is None else ops.LAUNCH_LOG[log0:]
         # The optimizer is ONE launch over every trainable tensor and writes the bf16 operands in the same pass
         # (packed_train.PackedAdamW, csrc/optim.hip); its table holds the addresses of the gradients the captured backward
         # left in `.grad`, which every replay re-writes in place.  It runs right behind the graph, followed by the one-launch
@@ -714,8 +774,14 @@ class GraphedFineTunerStep(FineTunerStep):
         from .packed_train import PackedAdamW
         self.optimizer = PackedAdamW(self.trainer, lr=self.opt_kw["lr"], betas=self.opt_kw["betas"], eps=self.opt_kw["eps"],
                                      weight_decay=self.opt_kw["weight_decay"])
-        self._cap = dict(st=st, graph=graph, **out)
+        self._cap = dict(st=st, graph=graph, launch_log=launch_log, **out)
+        if self._dp_graphed:
+            self.reducer = BucketedGradReducer(self.optimizer.params, self._bucket_bytes, mode=self._reduce_mode, hooks=False)
         return self
+
+    def graph_nodes(self):
+        """nodes of the captured teacher + student forward / backward graph, when it was kept (graph_utils.KEEP_GRAPHS)"""
+        return None if self._cap is None else {"fwd_bwd": node_count(self._cap["graph"])}
 
     def train_step(self, optimizer=None, batch: Optional[dict] = None):
         """one replayed step on `batch` (same shapes as the captured one); `optimizer` is ignored: the fused AdamW built at
@@ -727,5 +793,9 @@ class GraphedFineTunerStep(FineTunerStep):
                 cap["st"][k].copy_(batch[k])
             cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
         cap["graph"].replay()
+        if self._dp_graphed and self.reducer is not None:
+            self.reducer.exchange_all()          # mean over the ranks, written in place (the optimizer's table holds these addresses)
         self.optimizer.step()
-        return {"loss": cap["total"], "diff_loss": cap["diff"], "distillation_loss": cap["dist"], "block_loss": cap["blk"]}
+        # (clones: the graph's static outputs are overwritten by the next replay, and callers accumulate losses over steps)
+        return {"loss": cap["total"].clone(), "diff_loss": cap["diff"].clone(), "distillation_loss": cap["dist"].clone(),
+                "block_loss": cap["blk"].clone()}

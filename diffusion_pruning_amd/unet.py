@@ -122,10 +122,19 @@ class _CatSlot:
         return self.buf[..., :self.ch] if which == 0 else self.buf[..., self.ch:]
 
 
+def _ft_mode(mod) -> bool:
+    """The differentiable / fine-tuning forward is the one to run: autograd is on, or a PackedTrainer is attached.  Under a
+    PackedTrainer the packed tensors ARE the model (the diffusers-layout masters keep their initial values until
+    ``export_()`` and may sit in host memory), so a no-grad forward in the middle of training -- the reference FineTuner's
+    validation and sample generation, trainer.py:1766-1830 -- must read them too instead of inference packs built from
+    the stale masters; the autograd Functions of that path simply run their forward when grad is off."""
+    return torch.is_grad_enabled() or mod.__dict__.get("_pk") is not None
+
+
 def _take_dst(mod, B: int, H: int, W: int, C: int, device) -> Optional[torch.Tensor]:
     """destination view registered for this module's output by the model's forward (inference only), or None"""
     d = mod.__dict__.pop("_out_dst", None)
-    if d is None or torch.is_grad_enabled():
+    if d is None or _ft_mode(mod):
         return None
     return d[0].view(d[1], B, H, W, C, device)
 
@@ -418,7 +427,7 @@ class ResnetBlock2DWidthGated(nn.Module):
     def forward(self, input_tensor: torch.Tensor, temb, scale: float = 1.0):
         x = _nhwc(input_tensor)
         dst = _take_dst(self, x.shape[0], x.shape[1], x.shape[2], self.out_channels, x.device)
-        if torch.is_grad_enabled() and self.conv1.weight.requires_grad:
+        if _ft_mode(self) and self.conv1.weight.requires_grad:
             return self._forward_ft(x, temb)
         if self._needs_autograd(x):
             return self._forward_train(x, temb)
@@ -854,7 +863,7 @@ class Transformer2DModelWidthGated(nn.Module):
             raise NotImplementedError("attention masks are not used on the APTP path (pruning_pipelines.py:796-802)")
         x = _nhwc(hidden_states)
         dst = _take_dst(self, x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.device)
-        if torch.is_grad_enabled() and self.proj_in.weight.requires_grad:
+        if _ft_mode(self) and self.proj_in.weight.requires_grad:
             if self.depth_gated and (self.dropped or self._depth_state()[0] == 0.0):
                 return self._ret(hidden_states, return_dict)
             return self._ret(self._forward_ft(x, encoder_hidden_states), return_dict)
@@ -994,7 +1003,7 @@ class Downsample2D(nn.Module):
 
     def forward(self, hidden_states, scale: float = 1.0):
         x = _nhwc(hidden_states)
-        if torch.is_grad_enabled():
+        if _ft_mode(self):
             self.__dict__.pop("_out_dst", None)
         ver = _versions(self)
         if self._pw is None or self._pw.w.device != x.device or self._pw_ver != ver:
@@ -1003,7 +1012,7 @@ class Downsample2D(nn.Module):
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
             self._pwb, self._pw_ver, self._pinned = None, ver, False
         self._pinned = self._pinned or _capturing()
-        if torch.is_grad_enabled() and self.conv.weight.requires_grad:
+        if _ft_mode(self) and self.conv.weight.requires_grad:
             from . import autograd as AG
             return _nchw(_cw(self, x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), stride=2, pad=1))
         if torch.is_grad_enabled() and x.requires_grad:
@@ -1036,7 +1045,7 @@ class Upsample2D(nn.Module):
 
     def forward(self, hidden_states, output_size=None, scale: float = 1.0):
         x = _nhwc(hidden_states)
-        if torch.is_grad_enabled():
+        if _ft_mode(self):
             self.__dict__.pop("_out_dst", None)
         ver = _versions(self)
         if self._pw is None or self._pw.w.device != x.device or self._pw_ver != ver:
@@ -1045,7 +1054,7 @@ class Upsample2D(nn.Module):
             self._pw = ops.pack_weight(self.conv.weight.detach(), self.conv.bias.detach(), device=x.device)
             self._pwb, self._pw_ver, self._pinned = None, ver, False
         self._pinned = self._pinned or _capturing()
-        if torch.is_grad_enabled() and self.conv.weight.requires_grad:
+        if _ft_mode(self) and self.conv.weight.requires_grad:
             from . import autograd as AG
             return _nchw(_cw(self, x, self.conv.weight, self.conv.bias, self._pw, self._get_bwd(x.device), ups=1))
         if torch.is_grad_enabled() and x.requires_grad:
@@ -1369,6 +1378,14 @@ class UNet2DConditionModelGated(nn.Module):
         self.invalidate_plans()
         return out
 
+    def state_dict(self, *a, **k):
+        """(under a PackedTrainer the trained values live in the packed tensors: write them back into the diffusers-named
+        parameters first, so a checkpoint taken mid-training -- trainer.py:1767-1778 -- holds what was trained)"""
+        pk = self.__dict__.get("_pk")
+        if pk is not None:
+            pk.export_()
+        return super().state_dict(*a, **k)
+
     # ---- checkpoints in the reference's on-disk layout (diffusers ModelMixin API; checkpoint.py) -------------------
     def save_pretrained(self, save_directory: str, **unused):
         """``model.save_pretrained(os.path.join(output_dir, "unet"))`` as trainer.py:262-265 calls it: config.json +
@@ -1584,7 +1601,7 @@ class UNet2DConditionModelGated(nn.Module):
         CrossAttnUpBlock2D.forward torch.cat) reads, so the 12 concats of a forward are views instead of copies.  A
         producer that does not run its inference path (depth gate 0, autograd) simply ignores the slot and the consumer
         falls back to the copying concat.  Returns the destination of conv_in's output."""
-        if torch.is_grad_enabled():
+        if _ft_mode(self):
             return None                                  # (_take_dst drops any stale registration under autograd)
         skips = [None]                                   # conv_in is handled by the caller
         for blk in self.down_blocks:
@@ -1689,7 +1706,7 @@ class UNet2DConditionModelGated(nn.Module):
     def _forward_impl(self, sample, timestep, encoder_hidden_states, return_dict):
         dev = sample.device
         B = sample.shape[0]
-        if torch.is_grad_enabled() and self.conv_in.weight.requires_grad:
+        if _ft_mode(self) and self.conv_in.weight.requires_grad:
             return self._forward_ft(sample, timestep, encoder_hidden_states, return_dict)
         misc = self._misc_packs(dev)
         bp = self._batched_packs(dev)

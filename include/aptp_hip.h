@@ -177,7 +177,15 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        /* LDS-DMA ring, 8 waves as TWO copies of a 2 x 2 wave grid: copy 0 / 1 multiplies the first / second 32-wide half
         * of every K-tile (intra-workgroup split-K, summed through LDS before the epilogue); 3- or 4-stage ring */
        APTP_TILE_KS2S3_64x64 = 58, APTP_TILE_KS2S4_64x64 = 59, APTP_TILE_KS2S3_64x128 = 60, APTP_TILE_KS2S4_64x128 = 61,
-       APTP_TILE_KS2S3_128x64 = 62, APTP_TILE_KS2S3_128x128 = 63 };
+       APTP_TILE_KS2S3_128x64 = 62, APTP_TILE_KS2S3_128x128 = 63,
+       /* persistent stream-K macro-tiles (conv_gemm_sk.hip): one 8-wave workgroup per CU walks an equal share of the
+        * launch's (tile, K-step) units; split_k > 1 = K split on (needs workspace + tile_counters: partial tiles are
+        * combined in-kernel by the last arriver), split_k == 1 = whole tiles only.  Two wave groups alternate an LDS /
+        * load slot and a register-only MFMA slot per 32-deep K half; 3-stage LDS-DMA ring filled in half-tiles */
+       APTP_TILE_SK_256x160 = 64, APTP_TILE_SK_256x128 = 65, APTP_TILE_SK_128x256 = 66,
+       /* the same with a phase's fragment reads in its own load slot (beside the OTHER group's MFMAs) instead of one phase
+        * ahead beside the wave's own MFMAs: one register set, shorter DMA lead (tuner candidates) */
+       APTP_TILE_SKL_256x160 = 67, APTP_TILE_SKL_256x128 = 68, APTP_TILE_SKL_128x256 = 69 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

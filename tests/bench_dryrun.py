@@ -33,3 +33,29 @@ def install_train():
     real = UNet2DConditionModelGated(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
                                      cross_attention_dim=cfg.cross_attention_dim)
     return StubUNet(real), 16, 4
+
+
+class _StubFineTune:
+    """stand-in for train_step.GraphedFineTunerStep on CPU: a small trainable map fitted to a fixed target, one SGD step per
+    train_step -- enough for the launcher / rank -> expert mapping / record of ``bench.py --config finetune --dryrun-cpu``"""
+
+    def __init__(self, expert: int):
+        g = torch.Generator().manual_seed(1000 + expert)
+        self.w = torch.nn.Parameter(torch.randn(8, 8, generator=g) * 0.1)
+        self.t = torch.randn(4, 8, generator=g)
+        self.x = torch.randn(4, 8, generator=g)
+
+    def train_step(self, optimizer, batch):
+        loss = ((self.x @ self.w - self.t) ** 2).mean()
+        loss.backward()
+        with torch.no_grad():
+            self.w -= 0.05 * self.w.grad
+            self.w.grad = None
+        return {"loss": loss.detach()}
+
+
+def install_finetune(expert: int, batch: int):
+    """(step, batch, trainable parameters, keep ratio) of the stand-in expert"""
+    torch.set_num_threads(2)
+    step = _StubFineTune(expert)
+    return step, {"n": batch}, step.w.numel(), 0.4 + 0.05 * expert

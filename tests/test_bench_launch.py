@@ -46,6 +46,20 @@ def test_gpus2_spawns_two_ranks_pruning_step():
     assert rec["per_gpu_steps_per_s"] == pytest.approx(rec["value"] / 2, rel=1e-3)
 
 
+def test_gpus2_finetune_is_one_expert_per_rank_without_collectives():
+    """BASELINE configs[4]: rank r trains expert (r + offset) % 8; the ranks only meet in the timing barrier"""
+    rec = _line(_bench("--gpus", "2", "--dryrun-cpu", "--config", "finetune", "--steps", "3", "--warmup", "1", "--batch", "2"))
+    assert rec["n_gpus"] == 2 and "configs[4]" in rec["config"]["workload"]
+    assert [e["expert"] for e in rec["experts"]] == [0, 1] and [e["rank"] for e in rec["experts"]] == [0, 1]
+    assert rec["experts"][0]["keep_ratio"] == 0.4 and rec["experts"][1]["keep_ratio"] == 0.45
+    assert "no collective" in rec["config"]["parallelism"] and rec["scaling"] == "weak"
+    assert rec["value"] == pytest.approx(2 * 3 / (rec["ms_per_step"] * 3 * 1e-3), rel=1e-3)
+    one = _line(_bench("--dryrun-cpu", "--config", "finetune", "--steps", "2", "--warmup", "0", "--batch", "2"))
+    assert one["n_gpus"] == 1 and one["experts"][0]["expert"] == 3                # N = 1: expert 3
+    off = _line(_bench("--gpus", "2", "--dryrun-cpu", "--config", "finetune", "--steps", "1", "--warmup", "0", "--expert-offset", "6"))
+    assert [e["expert"] for e in off["experts"]] == [6, 7]
+
+
 def test_single_rank_default_and_world_size_mismatch():
     rec = _line(_bench("--dryrun-cpu", "--steps", "1", "--warmup", "0", "--latent", "16", "--batch", "1"))
     assert rec["n_gpus"] == 1

@@ -180,7 +180,7 @@ def test_data_parallel_pruner_step_keeps_replicas_in_sync():
     assert res[0]["loss"] != res[1]["loss"]                   # different data shards
 
 
-def _bucket_worker(rank, world):
+def _bucket_worker(rank, world, mode="all_reduce"):
     """BucketedGradReducer: buckets in reverse registration order, launched from post-accumulate hooks,
     mean written back into .grad; a parameter that received no gradient still takes part (zeros)."""
     from diffusion_pruning_amd.train_step import BucketedGradReducer
@@ -188,7 +188,7 @@ def _bucket_worker(rank, world):
     net = nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 16), nn.Linear(16, 4))
     unused = nn.Parameter(torch.ones(5))
     params = list(net.parameters()) + [unused]
-    red = BucketedGradReducer(params, bucket_bytes=300, wire_dtype=torch.float32)      # several small buckets
+    red = BucketedGradReducer(params, bucket_bytes=300, wire_dtype=torch.float32, mode=mode)      # several small buckets
     nb = len(red.buckets)
     x = torch.full((2, 8), float(rank + 1))
     net(x).sum().backward()
@@ -218,3 +218,48 @@ def test_bucketed_grad_reducer_means_gradients_across_ranks():
             assert torch.allclose(res[r][f"g{i}"], mean, atol=1e-6), i
     assert torch.equal(res[0]["unused"], torch.zeros(5))
     assert torch.equal(res[0]["g0_step2"], res[1]["g0_step2"])
+
+
+def _bucket_worker_rs_ag(rank, world):
+    return _bucket_worker(rank, world, mode="rs_ag")
+
+
+def test_bucketed_grad_reducer_reduce_scatter_all_gather_mode():
+    """mode "rs_ag" (the direct full-mesh exchange on xGMI): reduce-scatter + all-gather per bucket, bucket sizes
+    that are not multiples of the world size (padded shards), same means as the all-reduce form"""
+    res = _run(_bucket_worker_rs_ag)
+    assert res[0]["nb"] >= 3
+    n = sum(1 for k in res[0] if k.startswith("g") and k[1:].isdigit())
+    for i in range(n):
+        mean = (res[0][f"l{i}"] + res[1][f"l{i}"]) / 2
+        for r in (0, 1):
+            assert torch.allclose(res[r][f"g{i}"], mean, atol=1e-6), i
+    assert torch.equal(res[0]["unused"], torch.zeros(5))
+    assert torch.equal(res[0]["g0_step2"], res[1]["g0_step2"])
+
+
+def _exchange_all_worker(rank, world):
+    """hooks=False + exchange_all(): the form GraphedFineTunerStep(data_parallel=True) uses on the gradients a replayed
+    graph leaves behind -- means written IN PLACE (the optimizer's table holds the addresses), odd sizes, both modes"""
+    from diffusion_pruning_amd.train_step import BucketedGradReducer
+    out = {}
+    for mode in ("all_reduce", "rs_ag"):
+        torch.manual_seed(5)
+        ps = [nn.Parameter(torch.randn(s)) for s in ((7, 3), (5,), (64, 9), (1,))]
+        for p in ps:
+            p.grad = torch.full_like(p, float(rank + 1)) * p.detach()
+        ptrs = [p.grad.data_ptr() for p in ps]
+        red = BucketedGradReducer(ps, bucket_bytes=200, wire_dtype=torch.float32, mode=mode, hooks=False)
+        red.exchange_all()
+        red.exchange_all()                         # a second exchange of already equal gradients changes nothing
+        out[mode + "_inplace"] = all(p.grad.data_ptr() == q for p, q in zip(ps, ptrs))
+        out[mode] = torch.cat([(p.grad / p.detach()).flatten() for p in ps])
+    return out
+
+
+def test_exchange_all_without_hooks_writes_means_in_place():
+    res = _run(_exchange_all_worker)
+    for mode in ("all_reduce", "rs_ag"):
+        for r in (0, 1):
+            assert res[r][mode + "_inplace"]
+            assert torch.allclose(res[r][mode], torch.full_like(res[r][mode], 1.5), atol=1e-6)

@@ -137,6 +137,40 @@ def test_packed_masters_train_like_diffusers_layout_masters(cuda):
     assert abs(la2 - lb2) <= 2e-3 * abs(la2) and la2 != la
 
 
+def test_no_grad_forward_and_state_dict_follow_the_packed_state(cuda):
+    """While a PackedTrainer is attached, the packed tensors ARE the model: a no-grad forward in the middle of training (the
+    reference FineTuner's validation / sample generation, trainer.py:1766-1830) and state_dict() must see the trained values,
+    not inference packs built from the diffusers-layout masters, which keep their initial values until export_()."""
+    from diffusion_pruning_amd.packed_train import PackedTrainer
+    from diffusion_pruning_amd.train_step import FineTunerStep, synthetic_batch
+    mask = O.random_mask(O.TINY, 0.5, 8, n_depth_off=1)
+    cfg, sa, sb, teacher = _two_students(cuda, mask)
+    batch = synthetic_batch(2, 16, cuda, seed=4, cross_dim=cfg.cross_attention_dim)
+    args = (batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"])
+    with torch.no_grad():
+        y_init = sb(*args).sample.float().clone()
+    step = FineTunerStep(sb, teacher)
+    pk = PackedTrainer(sb).attach().materialize(*args)
+    opt = torch.optim.SGD(pk.parameters(), lr=5e-2)
+    for _ in range(2):
+        step.train_step(opt, batch)
+    y_grad = sb(*args).sample.detach().float()                     # the training forward: reads the packed state
+    with torch.no_grad():
+        y_eval = sb(*args).sample.float()
+    assert rel_l2(y_eval, y_grad) <= 1e-6                          # same packs, same kernels
+    assert rel_l2(y_eval, y_init) > 1e-3                           # and they did move
+    # the checkpoint interface exports first
+    w0 = dict(sa.named_parameters())["down_blocks.0.resnets.0.conv1.weight"].detach()
+    sd = sb.state_dict()
+    assert float((sd["down_blocks.0.resnets.0.conv1.weight"].to(cuda) - w0).abs().max()) > 0
+    # after detach() the inference path runs on packs rebuilt from the exported masters: same function again
+    pk.detach()
+    sb.invalidate_plans()
+    with torch.no_grad():
+        y_inf = sb(*args).sample.float()
+    check(rel_l2(y_inf, y_eval), 2e-2, "inference forward on exported masters vs no-grad forward on the packed state")
+
+
 def test_graphed_finetune_step_equals_the_eager_packed_step(cuda):
     """GraphedFineTunerStep (teacher forward; student forward + losses + backward + fused AdamW + operand refresh as HIP
     graphs) reproduces the eager packed step: losses of three consecutive steps and the parameters after them"""
@@ -239,3 +273,23 @@ def test_one_launch_adamw_matches_torch_adamw(cuda):
     opt2.load_state_dict(sd)
     opt2.step()
     assert all(torch.equal(p.detach(), a) for p, a in zip(ps, after)) and float(opt2.step_t) == 5.0
+    # entries are matched by NAME: a state saved in another order loads onto the right tensors; a moment of another shape
+    # (either list) or a state of another tensor list is refused
+    perm = [4, 2, 0, 3, 1]
+    sd_perm = {"step": sd["step"], "names": [sd["names"][i] for i in perm], "exp_avg": [sd["exp_avg"][i] for i in perm],
+               "exp_avg_sq": [sd["exp_avg_sq"][i] for i in perm]}
+    with torch.no_grad():
+        for p, s0 in zip(ps, snap):
+            p.copy_(s0)
+    opt3 = PackedAdamW(trainer, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    opt3.load_state_dict(sd_perm)
+    opt3.step()
+    assert all(torch.equal(p.detach(), a) for p, a in zip(ps, after))
+    bad = dict(sd)
+    bad["exp_avg_sq"] = [v.flatten()[:-1].clone() if i == 1 else v for i, v in enumerate(sd["exp_avg_sq"])]
+    with pytest.raises(AssertionError):
+        opt3.load_state_dict(bad)
+    other = dict(sd)
+    other["names"] = ["x" + n for n in sd["names"]]
+    with pytest.raises(AssertionError):
+        opt3.load_state_dict(other)

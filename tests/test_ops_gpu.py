@@ -308,6 +308,45 @@ CONV_CASES = [
     (4, 32, 32, 1280, 640, 3, 1, 0, 36, 3),
     (4, 32, 32, 640, 640, 3, 1, 0, 38, 1),
     (4, 32, 32, 640, 640, 3, 1, 0, 40, 1),
+    # persistent stream-K macro-tiles (64: 256x160, 65: 256x128, 66: 128x256; split_k 1 = whole tiles, 2 = K split on):
+    # fewer units than CUs, ragged tails, 1 / 2 / 3 K-steps (shorter than the DMA stream's head start), stride 2, folded
+    # upsample, tiles shared by 30+ workgroups (K = 180 / 360 steps on 8 / 5 tiles), full-size level-64 / 32 / 16 shapes
+    (2, 16, 16, 64, 64, 3, 1, 0, 64, 1),
+    (2, 16, 16, 64, 64, 3, 1, 0, 64, 2),
+    (3, 7, 5, 72, 40, 3, 1, 0, 64, 2),
+    (3, 7, 5, 72, 40, 3, 1, 0, 65, 1),
+    (3, 7, 5, 72, 40, 3, 1, 0, 66, 2),
+    (2, 16, 16, 64, 128, 1, 1, 0, 64, 2),
+    (2, 16, 16, 128, 128, 1, 1, 0, 65, 2),
+    (2, 16, 16, 192, 128, 1, 1, 0, 66, 2),
+    (2, 16, 16, 192, 200, 1, 1, 0, 64, 1),
+    (2, 16, 16, 128, 128, 3, 2, 0, 64, 2),
+    (2, 8, 8, 128, 128, 3, 1, 1, 65, 2),
+    (2, 8, 8, 128, 128, 3, 1, 1, 66, 1),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 64, 2),
+    (1, 8, 8, 2560, 1280, 3, 1, 0, 66, 2),
+    (4, 8, 8, 1280, 640, 3, 1, 0, 65, 2),
+    (2, 32, 32, 160, 320, 3, 1, 0, 64, 1),
+    (2, 32, 32, 160, 320, 3, 1, 0, 64, 2),
+    (4, 64, 64, 320, 320, 3, 1, 0, 64, 2),
+    (4, 64, 64, 320, 160, 3, 1, 0, 64, 2),
+    (4, 64, 64, 160, 320, 3, 1, 0, 65, 1),
+    (4, 32, 32, 1280, 640, 3, 1, 0, 64, 2),
+    (4, 32, 32, 640, 1280, 3, 1, 0, 66, 2),
+    (4, 16, 16, 1280, 1280, 1, 1, 0, 66, 2),
+    (4, 16, 16, 2560, 1280, 3, 1, 0, 64, 2),
+    (1, 32, 32, 4160, 200, 1, 1, 0, 64, 2),      # Cin beyond the 8 KiB zero page of the other LDS-DMA tiles
+    # the same macro-tiles with the fragment reads in the load slot (67..69)
+    (3, 7, 5, 72, 40, 3, 1, 0, 67, 2),
+    (2, 16, 16, 64, 128, 1, 1, 0, 68, 2),
+    (2, 16, 16, 128, 128, 1, 1, 0, 69, 1),
+    (2, 16, 16, 192, 128, 1, 1, 0, 67, 2),
+    (2, 16, 16, 128, 128, 3, 2, 0, 68, 2),
+    (2, 8, 8, 128, 128, 3, 1, 1, 69, 2),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, 67, 2),
+    (4, 64, 64, 320, 320, 3, 1, 0, 67, 2),
+    (4, 32, 32, 1280, 640, 3, 1, 0, 68, 2),
+    (4, 16, 16, 2560, 1280, 3, 1, 0, 69, 2),
 ]
 
 
@@ -363,6 +402,35 @@ def test_splitk_in_kernel_matches_reduce_launch_bitwise_and_is_stable(ops, cuda,
     assert int(ops._tile_counters(cuda).abs().sum()) == 0          # every launch left its counters at zero
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,k,tile", [(4, 16, 2560, 1280, 1, 64), (4, 8, 1280, 640, 3, 65), (4, 32, 320, 640, 3, 64),
+                                                 (1, 24, 64, 200, 3, 66), (4, 16, 640, 1280, 3, 66)])
+def test_streamk_is_stable_and_close_to_whole_tiles(ops, cuda, B, H, Cin, Cout, k, tile):
+    """The persistent stream-K tiles: a partial tile's ranges are summed in range order by whichever workgroup arrives last,
+    so many back-to-back launches -- interleaved with stream-K launches of another geometry on the same counters -- must be
+    BIT-identical (a stale slab line, a lost counter reset or a wrong contributor count would show as a differing or missing
+    tile); against the whole-tile form only the fp32 summation order differs."""
+    g = torch.Generator().manual_seed(B * H + Cin + Cout + tile)
+    x = nhwc(_rand((B, Cin, H, H), g)).bfloat16().to(cuda)
+    res = nhwc(_rand((B, Cout, H, H), g)).bfloat16().to(cuda)
+    pw = ops.pack_weight(_rand((Cout, Cin, k, k), g, 1.0 / math.sqrt(Cin * k * k)), _rand((Cout,), g, 0.1), device=cuda)
+    x2 = nhwc(_rand((2, 256, 8, 8), g)).bfloat16().to(cuda)
+    pw2 = ops.pack_weight(_rand((136, 256, 3, 3), g, 0.02), None, device=cuda)
+    whole = ops.conv_gemm(x, pw, residual=res, tile=tile, split_k=1)
+    ref = ops.conv_gemm(x, pw, residual=res, tile=tile, split_k=2).clone()
+    ref2 = ops.conv_gemm(x2, pw2, tile=64, split_k=2).clone()
+    assert rel_l2(ref.float(), whole.float()) <= 2e-3
+    out = torch.empty_like(ref)
+    bad = 0
+    for it in range(60):
+        ops.conv_gemm(x, pw, residual=res, tile=tile, split_k=2, out=out)
+        y2 = ops.conv_gemm(x2, pw2, tile=64, split_k=2)
+        if it % 6 == 5:
+            bad += int(not torch.equal(out, ref)) + int(not torch.equal(y2, ref2))
+    torch.cuda.synchronize()
+    assert bad == 0
+    assert int(ops._tile_counters(cuda).abs().sum()) == 0          # every launch left its counters at zero
+
+
 ORDER_CASES = [
     # B, H, W, Cin, Cout, k, tile, split_k : workgroup counts that are / are not multiples of 8, with and without split-K
     (2, 32, 32, 160, 320, 3, 10, 1),     # 32 x 2 tiles
@@ -371,6 +439,8 @@ ORDER_CASES = [
     (1, 8, 8, 1280, 1280, 3, 18, 5),     # 1 x 20 x 5
     (4, 16, 16, 320, 136, 3, 34, 2),     # ping-pong tile, 8 x 1 x 2
     (2, 40, 40, 64, 64, 1, 6, 1),        # 50 x 1 (register-staged kernel)
+    (4, 16, 16, 320, 136, 3, 64, 1),     # persistent macro-tile, whole tiles (with the K split the summation order follows the tile order)
+    (2, 32, 32, 128, 520, 1, 66, 1),
 ]
 
 
@@ -405,7 +475,7 @@ def test_conv_next_weight_prefetch_changes_nothing(ops, cuda, nbytes, tile):
 
 
 @pytest.mark.parametrize("tile,split_k", [(0, 1), (9, 1), (18, 1), (19, 1), (34, 1), (34, 2), (38, 1), (42, 1), (50, 1), (56, 1),
-                                          (58, 1), (60, 2), (63, 1)])
+                                          (58, 1), (60, 2), (63, 1), (64, 1), (64, 2), (65, 2), (66, 1)])
 @pytest.mark.parametrize("Cout", [320, 200])
 def test_groupnorm_takes_the_producer_column_statistics(ops, cuda, tile, split_k, Cout):
     """conv_gemm(colstats=True) leaves per-(row block, channel) sum / sum of squares of what it stored with the tensor
@@ -438,7 +508,7 @@ def test_groupnorm_takes_the_producer_column_statistics(ops, cuda, tile, split_k
     assert ops._colstats_get(y, Cout) is None
 
 
-@pytest.mark.parametrize("tile,split_k", [(0, 1), (9, 1), (19, 1), (34, 3), (25, 1), (50, 2), (56, 1), (59, 1), (63, 2)])
+@pytest.mark.parametrize("tile,split_k", [(0, 1), (9, 1), (19, 1), (34, 3), (25, 1), (50, 2), (56, 1), (59, 1), (63, 2), (64, 2), (65, 1), (66, 2)])
 @pytest.mark.parametrize("Cin2", [64, 200, 960])
 def test_conv_second_operand_segment(ops, cuda, tile, split_k, Cin2, both_splitk):
     """x2: conv3x3(x) + conv1x1(x2) in one launch (the resnet's conv_shortcut as extra K-steps of conv2)"""
@@ -471,8 +541,8 @@ def test_conv_strided_views(ops, cuda, both_epilogues):
     assert float(wide_out[..., :64].abs().max()) == 0.0 and float(wide_out[..., 160:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("split_k", [1, 3])
-def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues, both_splitk):
+@pytest.mark.parametrize("split_k,tile", [(1, 0), (3, 0), (2, 64), (1, 65), (2, 66)])
+def test_conv_full_epilogue(ops, cuda, split_k, tile, both_epilogues, both_splitk):
     """bias + temb rowbias + per-sample width gate, then (separately) corr + residual + depth lerp"""
     g = torch.Generator().manual_seed(11)
     B, H, W, Cin, Cout, G = 4, 8, 8, 64, 64, 32
@@ -483,7 +553,7 @@ def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues, both_splitk):
     temb = _rand((B, Cout), g, 0.5)
     gate = torch.rand((2, G), generator=g)                     # Bg=2 tiled over B=4 (CFG layout)
     y = ops.conv_gemm(nhwc(x).to(cuda), pw, rowbias=temb.to(cuda), colgate=gate.to(cuda).contiguous(),
-                      gate_group=Cout // G, split_k=split_k)
+                      gate_group=Cout // G, split_k=split_k, tile=tile)
     ref = F.conv2d(x.float(), w.float(), b, padding=1) + temb[:, :, None, None]
     mask = gate.repeat_interleave(Cout // G, dim=1).repeat(2, 1)[:, :, None, None]
     ref = ref * mask
@@ -494,7 +564,7 @@ def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues, both_splitk):
     d = torch.rand((2,), generator=g)
     corr = _rand((1, 9, Cout), g, 0.3)
     y = ops.conv_gemm(nhwc(x).to(cuda), pw, corr=corr.to(cuda).contiguous(), residual=nhwc(res).to(cuda),
-                      depth=d.to(cuda), depth_in=nhwc(din).to(cuda), split_k=split_k)
+                      depth=d.to(cuda), depth_in=nhwc(din).to(cuda), split_k=split_k, tile=tile)
     ref = F.conv2d(x.float(), w.float(), b, padding=1)
     cls = torch.ones(H, dtype=torch.long); cls[0] = 0; cls[-1] = 2
     cmap = cls[:, None] * 3 + cls[None, :]                      # [H, W]
@@ -505,7 +575,7 @@ def test_conv_full_epilogue(ops, cuda, split_k, both_epilogues, both_splitk):
     assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), ref) <= REL_L2_TOL
 
 
-@pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6), (1, 21), (2, 22), (1, 9), (1, 15), (1, 58), (2, 60), (1, 50)])
+@pytest.mark.parametrize("split_k,tile", [(1, 0), (2, 0), (1, 6), (1, 21), (2, 22), (1, 9), (1, 15), (1, 58), (2, 60), (1, 50), (2, 65), (1, 66), (2, 66)])
 def test_linear_geglu(ops, cuda, split_k, tile, both_epilogues, both_splitk):
     g = torch.Generator().manual_seed(13)
     B, L, C, inner = 2, 96, 64, 256
@@ -647,7 +717,8 @@ def test_layernorm(ops, cuda, rows, C):
 
 @pytest.mark.parametrize("rows,C,N,tile", [(96, 64, 64, 0), (200, 192, 320, 0), (2048, 128, 320, 9), (300, 640, 640, 21),
                                             (128, 320, 320, 34), (130, 640, 1280, 38), (256, 1280, 1280, 42),
-                                            (300, 640, 640, 58), (1024, 1280, 1280, 60)])
+                                            (300, 640, 640, 58), (1024, 1280, 1280, 60), (300, 640, 640, 64), (1024, 1280, 1280, 66),
+                                            (2048, 320, 320, 65)])
 def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile, both_epilogues):
     """the per-row (sum, sumsq) partials a producer GEMM emits (one slot per N-tile x wave column) add up to the
     statistics of the bf16 values it stored, for 4- and 8-wave tiles, ragged rows and a residual in the epilogue"""
@@ -684,7 +755,9 @@ def test_linear_emits_row_statistics(ops, cuda, rows, C, N, tile, both_epilogues
 @pytest.mark.parametrize("rows,C,N,tile,split_k,geglu", [(96, 64, 192, 0, 1, False), (200, 320, 384, 0, 1, False),
                                                          (2048, 320, 128, 18, 1, False), (256, 1280, 640, 25, 3, False),
                                                          (130, 640, 2560, 21, 1, True), (64, 1280, 5120, 40, 1, True),
-                                                         (300, 320, 1280, 9, 2, True), (1024, 1280, 1920, 59, 1, False), (300, 640, 2560, 61, 2, True)])
+                                                         (300, 320, 1280, 9, 2, True), (1024, 1280, 1920, 59, 1, False), (300, 640, 2560, 61, 2, True),
+                                                         (300, 640, 1280, 64, 2, False), (1024, 1280, 1920, 64, 1, False), (300, 640, 2560, 65, 2, True),
+                                                         (2048, 320, 2560, 66, 2, True)])
 def test_linear_with_folded_layernorm(ops, cuda, rows, C, N, tile, split_k, geglu, both_epilogues, both_splitk):
     """linear(LayerNorm(x)) in one launch (gamma folded into the weights, mean / rstd from the producer's row
     statistics) against F.layer_norm + F.linear in fp32 on the same bf16 x: blocks.py:782-785,808-813,821-823,41-50"""

@@ -16,20 +16,7 @@ from diffusion_pruning_amd.train_step import FineTunerStep, synthetic_batch  # n
 from diffusion_pruning_amd.unet import UNet2DConditionModelGated, UNet2DConditionModelPruned  # noqa: E402
 
 
-def expert_mask(structure, expert: int, device):
-    g = torch.Generator().manual_seed(1000 + expert)
-    keep = 0.4 + 0.05 * expert
-    width = []
-    for sub in structure["width"]:
-        for w in sub:
-            m = torch.zeros(1, w)
-            m[0, torch.randperm(w, generator=g)[:max(1, int(keep * w))]] = 0.9
-            width.append(m.to(device))
-    nd = sum(d for sub in structure["depth"] for d in sub)
-    depth = [torch.full((1,), 0.9, device=device) for _ in range(nd)]
-    for i in torch.randperm(nd, generator=g)[:expert % 5].tolist():
-        depth[i] = torch.zeros(1, device=device)
-    return {"width": width, "depth": depth}
+from bench import expert_mask  # noqa: E402,F401  (the eight benchmark experts live with the benchmark)
 
 
 def main():

@@ -450,3 +450,50 @@ def test_mse_inside_replayed_graphs_matches_eager(cuda):
         torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert all(torch.equal(v, eager) for v in vals)
+
+
+def test_standalone_gate_forward_is_the_reference_forward(ops, cuda):
+    """WidthGate / LinearWidthGate / DepthGate as modules of their own (pdm/models/unet/gates.py:15-21,36-42,49-55), incl. the
+    classifier-free-guidance batch doubling (gate batch 2, activation batch 4), through the HIP gate kernels, differentiably"""
+    from diffusion_pruning_amd.gates import DepthGate, LinearWidthGate, WidthGate
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, G = 4, 64, 8, 8, 32
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+    gate = WidthGate(G)
+    gf = torch.rand(2, G, generator=g).to(cuda).requires_grad_()
+    gate.set_structure_value(gf)
+    y = gate(x)
+    mask = gf.detach().float().repeat_interleave(C // G, dim=1)[:, :, None, None].repeat(2, 1, 1, 1)
+    ref = mask * x.detach().float()
+    assert y.shape == x.shape and float((y.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    R = torch.randn(B, C, H, W, generator=g).to(cuda)
+    (y.float() * R).sum().backward()
+    dgate_ref = (R * x.detach().float()).view(2, 2, G, C // G, H, W).sum(dim=(0, 3, 4, 5))
+    assert float((gf.grad - dgate_ref).abs().max()) <= 2e-2 * float(dgate_ref.abs().max())
+    assert float((x.grad.float() - mask * R).abs().max()) <= 2e-2 * float(R.abs().max())
+    # tokens
+    t = torch.randn(B, 40, C, generator=g).bfloat16().to(cuda)
+    lg = LinearWidthGate(G)
+    lg.set_structure_value(gf.detach())
+    yt = lg(t)
+    reft = gf.detach().float().repeat_interleave(C // G, dim=1)[:, None, :].repeat(2, 1, 1) * t.float()
+    assert float((yt.float() - reft).abs().max()) <= 2e-2 * float(reft.abs().max())
+    # depth gate
+    a = torch.randn(B, C, H, W, generator=g).bfloat16().to(cuda)
+    b = torch.randn(B, C, H, W, generator=g).bfloat16().to(cuda)
+    dg = DepthGate(1)
+    d = torch.tensor([0.25, 0.9], device=cuda, requires_grad=True)
+    dg.set_structure_value(d)
+    yd = dg((a, b))
+    dm = d.detach().repeat(2)[:, None, None, None]
+    refd = (1 - dm) * a.float() + dm * b.float()
+    assert float((yd.float() - refd).abs().max()) <= 2e-2 * float(refd.abs().max())
+    yd.float().sum().backward()
+    dd_ref = (b.float() - a.float()).view(2, 2, -1).sum(dim=(0, 2))
+    assert float((d.grad - dd_ref).abs().max()) <= 2e-2 * float(dd_ref.abs().max()) + 1e-2
+    # the default state (all ones) is the identity; tensors the kernels do not take are refused, not silently computed elsewhere
+    assert torch.equal(WidthGate(G).forward(x.detach()), x.detach())
+    with pytest.raises(TypeError):
+        gate(x.detach().float())
+    with pytest.raises(TypeError):
+        gate(x.detach().cpu())

@@ -215,6 +215,8 @@ TUNING_NEAREST = os.environ.get("APTP_TUNING_NEAREST", "1") != "0"
 TUNING_MAX_DIST = 2.0
 _HALO_TILES = (43, 44)
 SK_TILE_FIRST = 64          # APTP_TILE_SK_*: persistent stream-K macro-tiles (csrc/conv_gemm_sk.hip)
+SK_AUTO = os.environ.get("APTP_SK_AUTO", "1") == "1"
+SK_AUTO_MIN_OUTPUTS = 256 * 256 * 160
 _tuning_index = None
 _tuning_near_cache = {}
 
@@ -556,6 +558,17 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             in_kernel = bool(tuned.get("in_kernel", 0))
             if order == 0:
                 p.order = tuned.get("order", 1)     # tables tuned before the XCD-aware orders existed mean the legacy order
+    if split_k is None and tile == 0 and p.tile == 0 and SK_AUTO:
+        # no table entry: contractions with >= SK_AUTO_MIN_OUTPUTS outputs (a chip-filling number of 256 x 160 macro-tiles) and
+        # a long K take the persistent stream-K macro-tiles -- measured 1.28-1.42x the best per-tile launch on such shapes
+        # (tools/bench_sk.py: 16384 x 1280 x 11520 at 1,093 TFLOP/s; 8192^3 at 995 against 744) -- and nothing below that
+        # size does (0.5-0.98x on every launch of the bs=4 forward, which is why the table holds none)
+        nK = pw.KH * pw.KW * (pw.cin_pad // BK) + pw.cin2_pad // BK
+        if B * Hout * Wout * pw.N >= SK_AUTO_MIN_OUTPUTS and nK >= 16 and max(pw.cin_pad, pw.cin2_pad) <= 32704:
+            p.tile = SK_TILE_FIRST + 1 if act == ACT_GEGLU else SK_TILE_FIRST      # 256 x 128 for GEGLU's (h, g) column pairs
+            split_k, in_kernel = 2, True
+            if order == 0:
+                p.order = 3
     if split_k is None:
         split_k = lib.aptp_conv_gemm_suggest_split_k(ctypes.byref(p))
     p.split_k = max(1, int(split_k))

@@ -282,6 +282,7 @@ class PrunerStep:
         arch_vector = self.hyper_net(text_embeddings)                                           # :1129
         arch_vector_quantized, _ = self.quantizer(arch_vector)                                  # :1130
         arch_vector = self.quantizer.gumbel_sigmoid_trick(arch_vector)                          # :1132
+        arch_vector = self._single_arch_repeat(arch_vector, text_embeddings.shape[0])           # :1134-1136
         arch_wdn = self.quantizer.width_depth_normalize(arch_vector)                            # :1138
         text_all, arch_all = gather_with_local_grad(text_embeddings, arch_wdn)                  # :1147-1162 (one collective)
         sep = self.hyper_net.transform_structure_vector(arch_vector if pretrain else arch_vector_quantized)   # :1165-1168
@@ -324,6 +325,15 @@ class PrunerStep:
                 "block_loss": block_loss.detach(), "contrastive_loss": contrastive_loss.detach(),
                 "resource_loss": resource_loss.detach(), "resource_ratio": ratios.mean().detach(),
                 "arch_vector_quantized": arch_vector_quantized.detach()}
+
+    def _single_arch_repeat(self, arch_vector, batch: int):
+        """trainer.py:1134-1136 (the single-architecture baseline): the ONE learned architecture vector serves the whole batch
+        -- repeated after the Gumbel-sigmoid relaxation, so every sample sees the same noise draw -- and is remembered on the
+        hyper-net as ``arch_gs``"""
+        if getattr(self.hyper_net, "single_arch_param", False):
+            arch_vector = arch_vector.repeat(batch, 1)
+            self.hyper_net.arch_gs = arch_vector
+        return arch_vector
 
     def trainable_parameters(self):
         return [p for p in list(self.hyper_net.parameters()) + list(self.quantizer.parameters()) if p.requires_grad]
@@ -503,6 +513,7 @@ class GraphedPrunerStep(PrunerStep):
         arch_vector = self.hyper_net(text_embeddings)
         arch_vector_quantized, _ = self.quantizer(arch_vector)
         arch_vector = self.quantizer.gumbel_sigmoid_trick(arch_vector)
+        arch_vector = self._single_arch_repeat(arch_vector, text_embeddings.shape[0])
         arch_wdn = self.quantizer.width_depth_normalize(arch_vector)
         text_all, arch_all = gather_with_local_grad(text_embeddings, arch_wdn)
         arch_used = arch_vector if pretrain else arch_vector_quantized                          # trainer.py:1165-1168

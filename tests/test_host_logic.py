@@ -431,3 +431,32 @@ def test_scratch_domain_is_thread_local_and_restores():
             assert ops._domain() == "inner"
         assert ops._domain() == "teacher"
     assert ops._domain() is None and seen["other"] is None
+
+
+def test_single_arch_param_baseline_repeats_one_code_over_the_batch():
+    """trainer.py:1134-1136: with ``HyperStructure(single_arch_param=True)`` the one learned architecture vector is repeated over
+    the batch AFTER the Gumbel-sigmoid relaxation (every sample sees the same noise draw), kept as ``hyper_net.arch_gs``, and
+    its gradient reaches the single parameter"""
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+    from diffusion_pruning_amd.train_step import PrunerStep, synthetic_batch
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    from tests.test_distributed_cpu import DEPTH_ORDER, StubUNet
+    cfg = O.TINY
+    real = UNet2DConditionModelGated(block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.num_heads,
+                                     cross_attention_dim=cfg.cross_attention_dim)
+    torch.manual_seed(1)
+    hn = HyperStructure(structure=real.get_structure(), input_dim=16, single_arch_param=True)
+    qz = StructureVectorQuantizer(n_e=4, structure=real.get_structure(), temperature=0.4, base=3, depth_order=DEPTH_ORDER,
+                                  resource_aware_normalization=False, optimal_transport=False)
+    step = PrunerStep(StubUNet(real), hn, qz)
+    hn.train(); qz.train()
+    step.count_macs(8)
+    batch = synthetic_batch(3, 8, "cpu", seed=5, cross_dim=cfg.cross_attention_dim, text_dim=16)
+    torch.manual_seed(3)
+    out = step.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"], batch["mpnet_embeddings"],
+                    batch["target"], pretrain=True)
+    E = sum(hn.width_list) + sum(hn.depth_list)
+    assert hn.arch_gs.shape == (3, E) and torch.equal(hn.arch_gs[0], hn.arch_gs[1]) and torch.equal(hn.arch_gs[0], hn.arch_gs[2])
+    out["loss"].backward()
+    assert hn.arch.grad is not None and float(hn.arch.grad.abs().sum()) > 0 and torch.isfinite(out["loss"])

@@ -1,0 +1,182 @@
+"""The GRAPHED training steps -- what bench.py's `train` and `finetune` figures are measured on -- against the oracle at the
+FULL SD-2.1 size and the benchmarked batch (bs=4), reading gradients back AFTER a graph replay (not the capture pass):
+
+* configs[2]: GraphedPrunerStep, U-Net loss terms only: the [B, 1634] gate-gradient buffer of the captured backward, and the
+  hyper-net gradients it turns into, vs PyTorch autograd through the fp32 CPU oracle driven by the same step logic;
+* configs[4]: GraphedFineTunerStep: every packed parameter gradient of a 55 %-keep expert vs oracle autograd in pruned semantics,
+  then a SECOND step whose losses must be those of the parameters the first optimizer step produced (exported and re-evaluated by
+  the oracle): a stale bf16 operand / plan would reproduce the first step's loss instead."""
+import copy
+
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+from tests.margins import check  # noqa: E402
+from tests.test_train_step_gpu import DEPTH_ORDER, OracleUNetAdapter  # noqa: E402
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def test_graphed_pruning_step_full_size_bs4(cuda):
+    from diffusion_pruning_amd.hypernet import HyperStructure
+    from diffusion_pruning_amd.quantizer import StructureVectorQuantizer
+    from diffusion_pruning_amd.train_step import GraphedPrunerStep, PrunerStep, PruningLossConfig, synthetic_batch
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated
+    cfg = O.SD21
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    unet = UNet2DConditionModelGated().init_synthetic(seed=0)
+    params = {k: v.detach().clone() for k, v in unet.state_dict().items()}
+    st = unet.get_structure()
+    torch.manual_seed(11)
+    hn = HyperStructure(structure=st, input_dim=768, wn_flag=False, linear_bias=True)
+    qz = StructureVectorQuantizer(n_e=8, structure=st, temperature=0.4, base=3, depth_order=DEPTH_ORDER,
+                                  resource_aware_normalization=False, optimal_transport=True)
+    hn_ref, qz_ref = copy.deepcopy(hn), copy.deepcopy(qz)
+    unet.to(cuda).freeze()
+    hn.to(cuda); qz.to(cuda)
+    hn.train(); qz.train(); hn_ref.train(); qz_ref.train()
+    lcfg = PruningLossConfig(resource_weight=0.0, contrastive_weight=0.0, std_weight=0.0, max_weight=0.0)
+    B = 4
+    other = synthetic_batch(B, 64, cuda, seed=2)
+    batch_cpu = synthetic_batch(B, 64, "cpu", seed=7)
+    batch = {k: v.to(cuda) for k, v in batch_cpu.items()}
+    step = GraphedPrunerStep(unet, hn, qz, lcfg)
+    step.count_macs(64)
+    step.capture(other)
+    args = lambda b: (b["noisy_latents"], b["timesteps"], b["encoder_hidden_states"], b["mpnet_embeddings"], b["target"])  # noqa: E731
+    step.backward(step.step(*args(other), pretrain=True))           # a first replay on the captured batch
+    for p_ in step.trainable_parameters():
+        p_.grad = None
+    torch.manual_seed(123)
+    out = step.step(*args(batch), pretrain=True)                    # the replay under test: another batch, another code
+    step.backward(out)
+    torch.cuda.synchronize()
+    gate_grad = step._cap["grad"].detach().float().cpu().clone()   # [B, 1634], architecture-vector order
+
+    ref_unet = OracleUNetAdapter(params, cfg)
+    seen = {}
+    plain_set = ref_unet.set_structure
+
+    def set_structure(sep):                                        # keep the student's gate tensors to read their gradients
+        if any(t.requires_grad for t in sep["width"]):
+            seen["gates"] = list(sep["width"]) + list(sep["depth"])
+            for t in seen["gates"]:
+                t.retain_grad()
+        plain_set(sep)
+    ref_unet.set_structure = set_structure
+    ref = PrunerStep(ref_unet, hn_ref, qz_ref, lcfg)
+    ref.count_macs(64)
+    torch.manual_seed(123)
+    out_ref = ref.step(*args(batch_cpu), pretrain=True)
+    out_ref["loss"].backward()
+    for k in ("diff_loss", "distillation_loss", "block_loss"):
+        a, b = float(out[k]), float(out_ref[k])
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (k, a, b)
+    gref = torch.cat([t.grad.reshape(B, -1) for t in seen["gates"]], dim=1)
+    assert gref.shape == gate_grad.shape == (B, 1634)
+    check(rel_l2(gate_grad, gref), 6e-2, "gate-gradient buffer [4, 1634] after a graph replay (full size, bs=4)")
+    per_sample = max(rel_l2(gate_grad[i], gref[i]) for i in range(B))
+    check(per_sample, 8e-2, "worst sample of the gate-gradient buffer")
+    g = torch.cat([p_.grad.float().cpu().flatten() for p_ in hn.parameters()])
+    g_ref = torch.cat([p_.grad.flatten() for p_ in hn_ref.parameters()])
+    assert float(g_ref.abs().sum()) > 0
+    e = rel_l2(g, g_ref)
+    assert e > 1e-5, e
+    check(e, 8e-2, "hyper-net gradients through the U-Net terms (full size, bs=4, graph replay)")
+
+
+def test_graphed_finetune_step_full_size_bs4_gradients_and_second_step(cuda):
+    from diffusion_pruning_amd.train_step import FineTunerStep, FinetuneLossConfig, GraphedFineTunerStep, synthetic_batch
+    from diffusion_pruning_amd.unet import UNet2DConditionModelGated, UNet2DConditionModelPruned
+    cfg = O.SD21
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    mask = O.random_mask(cfg, 0.55, 4, n_depth_off=3)
+    teacher = UNet2DConditionModelGated().init_synthetic(seed=0)
+    params0 = {k: v.detach().clone() for k, v in teacher.state_dict().items()}
+    student = UNet2DConditionModelPruned()
+    student.load_state_dict(teacher.state_dict())
+    teacher.to(cuda).freeze()
+    teacher.set_structure({k: [v.to(cuda) for v in vs] for k, vs in O.ones_mask(cfg).items()})
+    student.to(cuda)
+    student.prune({k: [v.clone().to(cuda) for v in vs] for k, vs in mask.items()})
+    B = 4
+    other = synthetic_batch(B, 64, cuda, seed=2)
+    batch_cpu = synthetic_batch(B, 64, "cpu", seed=9)
+    batch = {k: v.to(cuda) for k, v in batch_cpu.items()}
+    lcfg = FinetuneLossConfig()
+    step = GraphedFineTunerStep(student, teacher, lcfg, lr=1e-3, weight_decay=0.0)
+    step.capture(other, offload_masters=True)
+    out1 = step.train_step(None, batch)                      # replay on a batch the capture never saw + AdamW
+    torch.cuda.synchronize()
+    loss1 = {k: float(v) for k, v in out1.items()}
+
+    # ---- oracle side: the same step logic on the fp32 oracle (pruned student, dense teacher), initial parameters ----------------
+    def oracle_losses(pstudent, with_grad):
+        sp = {k: v.detach().clone().requires_grad_(with_grad) for k, v in pstudent.items()}
+        s_ad = OracleUNetAdapter(sp, cfg, "pruned")
+        s_ad.set_structure({k: [v.clone() for v in vs] for k, vs in mask.items()})
+        t_ad = OracleUNetAdapter(params0, cfg, "gated")
+        t_ad.set_structure({k: [v.clone() for v in vs] for k, vs in O.ones_mask(cfg).items()})
+        ref = FineTunerStep(s_ad, t_ad, lcfg)
+        with torch.set_grad_enabled(with_grad):
+            o = ref.step(batch_cpu["noisy_latents"], batch_cpu["timesteps"], batch_cpu["encoder_hidden_states"], batch_cpu["target"])
+        return sp, o
+    sp, o_ref = oracle_losses(params0, True)
+    o_ref["loss"].backward()
+    for k in ("loss", "diff_loss", "distillation_loss", "block_loss"):
+        a, b = loss1[k], float(o_ref[k])
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, ("step 1", k, a, b)
+
+    # ---- packed gradients left by the replay vs oracle autograd ------------------------------------------------------------------
+    names = {id(p_): n for n, p_ in student.named_parameters()}
+    errs, got_all, ref_all = {}, [], []
+
+    def add(name, g, r):
+        if float(r.abs().sum()) == 0.0:
+            assert float(g.abs().sum()) == 0.0, name
+            return
+        assert torch.isfinite(g).all(), name
+        errs[name] = rel_l2(g, r)
+        got_all.append(g.flatten()); ref_all.append(r.flatten())
+    for e in step.trainer.gemms.values():
+        n = names[id(e.weight)]
+        r = sp[n].grad
+        r4 = r if r.dim() == 4 else r[:, :, None, None]
+        if e.lo is not None:
+            r4 = r4[e.lo.cpu()]
+        if e.li is not None:
+            r4 = r4[:, e.li.cpu()]
+        g = e.P.grad[:e.n_live, :, :e.c_live].float().cpu().permute(0, 2, 1).reshape(e.n_live, e.c_live, e.KH, e.KW)
+        add(n, g, r4)
+        if e.Pb is not None and e.bias is not None:
+            rb = sp[names[id(e.bias)]].grad
+            rb = rb[e.lo.cpu()] if e.lo is not None else rb
+            add(names[id(e.bias)], e.Pb.grad[:e.n_live].float().cpu(), rb)
+    for a in step.trainer.affines.values():
+        for P, full in ((a.Pg, a.gamma_p), (a.Pb, a.beta_p)):
+            r = sp[names[id(full)]].grad
+            r = r[a.live.cpu()] if a.live is not None else r
+            add(names[id(full)], P.grad.float().cpu()[:r.numel()], r)
+    assert len(errs) > 300
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    check(rel_l2(torch.cat(got_all), torch.cat(ref_all)), 6e-2, "all packed parameter gradients after a graph replay (bs=4)")
+    check(sorted(errs.values())[len(errs) // 2], 6e-2, "median packed parameter")
+    check(worst[0][1], 0.3, "worst packed parameter " + worst[0][0])
+
+    # ---- second step: the forward must run on what the optimizer wrote ------------------------------------------------------------
+    p1 = {k: v.detach().float().cpu().clone() for k, v in student.state_dict().items()}   # (exports the packed state: after step 1)
+    out2 = step.train_step(None, batch)                      # forward on the parameters of step 1, then AdamW again
+    torch.cuda.synchronize()
+    loss2 = {k: float(v) for k, v in out2.items()}
+    _, o2 = oracle_losses(p1, False)
+    for k in ("loss", "diff_loss", "distillation_loss", "block_loss"):
+        a, b = loss2[k], float(o2[k])
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, ("step 2", k, a, b)
+    # the check has teeth: lr 1e-3 moved the loss by far more than the tolerance, so a forward on stale operands (step 1's
+    # loss again) could not pass
+    assert abs(loss2["loss"] - loss1["loss"]) > 0.15 * abs(loss1["loss"]), (loss1["loss"], loss2["loss"])

@@ -27,9 +27,9 @@ class OracleUNetAdapter:
     oracle/macs_oracle.py -- an implementation independent of the product's macs.py -- so the resource / std / max loss
     terms of the two steps are a real comparison."""
 
-    def __init__(self, params, cfg):
+    def __init__(self, params, cfg, semantics: str = "gated"):
         from oracle import macs_oracle
-        self.params, self.cfg, self.M = params, cfg, macs_oracle
+        self.params, self.cfg, self.M, self.semantics = params, cfg, macs_oracle, semantics
         self.down_blocks = nn.ModuleList([_Pass() for _ in range(4)])
         self.mid_block = _Pass()
         self.up_blocks = nn.ModuleList([_Pass() for _ in range(4)])
@@ -43,7 +43,7 @@ class OracleUNetAdapter:
         self.gates = O.assign_gates(self.cfg, {"width": list(w), "depth": list(d)})
 
     def __call__(self, sample, t, ehs):
-        out, blocks = O.unet_forward(self.params, self.cfg, sample, t, ehs, self.gates, "gated", return_blocks=True)
+        out, blocks = O.unet_forward(self.params, self.cfg, sample, t, ehs, self.gates, self.semantics, return_blocks=True)
         for i in range(4):
             self.down_blocks[i]((blocks[i], None))
         self.mid_block(blocks[4])
@@ -121,6 +121,60 @@ def test_pruning_step_matches_oracle_driven_step(cuda):
     g_ref = torch.cat([p.grad.flatten() for p in hn_ref.parameters()])
     assert torch.isfinite(g).all() and float(g_ref.abs().sum()) > 0
     check(rel_l2(g, g_ref), 8e-2, "hyper-net gradients")
+
+
+@pytest.mark.parametrize("pretrain", [True, False])
+def test_router_gradients_through_the_unet_terms_only(cuda, pretrain):
+    """With resource / contrastive / std / max weights at zero, every router gradient has to come THROUGH the U-Net: gate
+    gradients of the captured backward -> segment-major buffer -> [B, 1634] order -> hyper-net heads (pretrain) or the
+    straight-through codebook path (quantised code).  In the default configuration those terms are invisible next to the
+    contrastive term (weight 100), so a mis-ordered segment or a sign error in that chain would pass the test above.  Replayed
+    graphs (the second replay, on another batch than the captured one) against the oracle-driven step."""
+    from diffusion_pruning_amd.train_step import GraphedPrunerStep, PrunerStep, PruningLossConfig, synthetic_batch
+    cfg, unet, params, hn, qz = build(cuda)
+    hn_ref, qz_ref = copy.deepcopy(hn), copy.deepcopy(qz)
+    unet.to(cuda).freeze()
+    hn.to(cuda); qz.to(cuda)
+    lcfg = PruningLossConfig(resource_weight=0.0, contrastive_weight=0.0, std_weight=0.0, max_weight=0.0)
+    other = synthetic_batch(4, 16, cuda, seed=2, cross_dim=cfg.cross_attention_dim, text_dim=32)
+    batch_cpu = synthetic_batch(4, 16, "cpu", seed=7, cross_dim=cfg.cross_attention_dim, text_dim=32)
+    batch_gpu = {k: v.to(cuda) for k, v in batch_cpu.items()}
+    hn.train(); qz.train()
+    step = GraphedPrunerStep(unet, hn, qz, lcfg)
+    step.count_macs(16)
+    step.capture(other)
+    step.backward(step.step(other["noisy_latents"], other["timesteps"], other["encoder_hidden_states"], other["mpnet_embeddings"],
+                            other["target"], pretrain=pretrain))
+    for p_ in step.trainable_parameters():
+        p_.grad = None
+    torch.manual_seed(123)
+    out = step.step(batch_gpu["noisy_latents"], batch_gpu["timesteps"], batch_gpu["encoder_hidden_states"],
+                    batch_gpu["mpnet_embeddings"], batch_gpu["target"], pretrain=pretrain)
+    step.backward(out)
+    torch.cuda.synchronize()
+
+    ref = PrunerStep(OracleUNetAdapter(params, cfg), hn_ref, qz_ref, lcfg)
+    hn_ref.train(); qz_ref.train()
+    ref.count_macs(16)
+    torch.manual_seed(123)
+    out_ref = ref.step(batch_cpu["noisy_latents"], batch_cpu["timesteps"], batch_cpu["encoder_hidden_states"],
+                       batch_cpu["mpnet_embeddings"], batch_cpu["target"], pretrain=pretrain)
+    out_ref["loss"].backward()
+    for k in ("diff_loss", "distillation_loss", "block_loss"):
+        a, b = float(out[k]), float(out_ref[k])
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (k, a, b)
+    got, want = [], []
+    for (n, p_), (_, q_) in zip(list(hn.named_parameters()) + list(qz.named_parameters()),
+                                list(hn_ref.named_parameters()) + list(qz_ref.named_parameters())):
+        if q_.grad is None or float(q_.grad.abs().sum()) == 0.0:
+            assert p_.grad is None or float(p_.grad.abs().sum()) == 0.0, n
+            continue
+        assert p_.grad is not None, n
+        got.append(p_.grad.float().cpu().flatten()); want.append(q_.grad.flatten())
+    assert want, "no router gradient reached through the U-Net terms"
+    e = rel_l2(torch.cat(got), torch.cat(want))
+    assert e > 1e-5, e          # bf16 U-Net gradients are in this number (the default-weights test sees ~2e-6)
+    check(e, 8e-2, "router gradients through the U-Net terms only (pretrain=%s)" % pretrain)
 
 
 def test_two_optimizer_steps_change_the_router(cuda):

@@ -164,9 +164,9 @@ def tune(args, lib, log):
         else:
             timer = lambda q: time_launch(lib, q)
         t_base = timer(base)
-        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18, 21, 22, 24, 25, 26, 27, 30, 31, 32, 35, 36, 38, 40] if p0.act == ACT_GEGLU else list(range(1, 64))
+        tiles = [1, 3, 5, 6, 7, 9, 11, 12, 13, 15, 17, 18, 21, 22, 24, 25, 26, 27, 30, 31, 32, 35, 36, 38, 40] if p0.act == ACT_GEGLU else list(range(1, 70))
         if p0.act == ACT_GEGLU:
-            tiles += [45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 57, 58, 59, 60, 61, 62, 63]
+            tiles += [45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 57, 58, 59, 60, 61, 62, 63, 65, 66, 68, 69]
         if args.tiles:
             tiles = [int(v) for v in args.tiles.split(",") if int(v) in tiles]
         splits = [1, 2, 3, 4, 6, 8, 12, 16, 24]
@@ -179,10 +179,14 @@ def tune(args, lib, log):
         best = (t_base, base.tile, base.split_k, base.order, 1 if base.tile_counters else 0)
         for tl in tiles:
             for sk in splits:
-                if sk > 1 and (nK // sk < 3 or (M + 255) * (p0.N + 255) * sk * 4 > ws.numel() or M >= 8192 and sk > 2):
+                if tl >= ops.SK_TILE_FIRST:
+                    # persistent stream-K macro-tiles: split_k is a switch (1 = whole tiles, 2 = K split on), always in-kernel
+                    if sk > 2 or (sk == 2 and nK < 2):
+                        continue
+                elif sk > 1 and (nK // sk < 3 or (M + 255) * (p0.N + 255) * sk * 4 > ws.numel() or M >= 8192 and sk > 2):
                     continue
                 for order in ((2, 3) if args.orders else (0,)):     # XCD-aware workgroup orders: weight- / activation-major
-                    for ink in ((1, 0) if (args.modes and sk > 1) else (1,)):
+                    for ink in ((1, 0) if (args.modes and sk > 1 and tl < ops.SK_TILE_FIRST) else (1,)):
                         q = clone_params(p0)
                         q.tile, q.split_k, q.order = tl, sk, order
                         q.workspace = ws.data_ptr() if sk > 1 else None

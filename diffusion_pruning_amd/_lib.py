@@ -50,6 +50,7 @@ class ConvGemmParams(Structure):
         ("epilogue", c_int32),
         ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_groups", c_int32), ("gn_C", c_int32), ("gn_silu", c_int32),
         ("gn_eps", c_float),
+        ("io_f32", c_int32),
     ]
 
 
@@ -67,6 +68,7 @@ class GroupNormParams(Structure):
         ("workspace", c_void_p), ("variant", c_int32),
         ("counters", c_void_p),
         ("colstats", GroupNormColStats * 2),
+        ("io_f32", c_int32),
     ]
 
 
@@ -77,6 +79,7 @@ class LayerNormParams(Structure):
         ("rows", c_int32), ("C", c_int32),
         ("gamma", c_void_p), ("beta", c_void_p),
         ("eps", c_float),
+        ("io_f32", c_int32),
     ]
 
 
@@ -90,6 +93,7 @@ class AttentionParams(Structure):
         ("scale", c_float),
         ("lse", c_void_p),
         ("variant", c_int32),
+        ("io_f32", c_int32),
     ]
 
 
@@ -132,6 +136,7 @@ class WgradParams(Structure):
         ("x", c_void_p), ("ldx", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("dw", c_void_p),
         ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("N", c_int32), ("KH", c_int32), ("KW", c_int32),
         ("split_m", c_int32), ("ld_dw", c_int32), ("db", c_void_p), ("slab_stride", c_int64), ("db_stride", c_int64),
+        ("stride", c_int32), ("ups", c_int32),
     ]
 
 

@@ -14,6 +14,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 void aptp_set_error(const char* fmt, ...);
 
+// fp32 parity instantiations (parity_f32.hip), reached through io_f32 of the public parameter blocks
+int aptp_groupnorm_f32(const AptpGroupNormParams* p, aptp_stream_t stream);
+int aptp_layernorm_f32(const AptpLayerNormParams* p, aptp_stream_t stream);
+int aptp_attention_f32(const AptpAttentionParams* p, aptp_stream_t stream);
+
 #define APTP_CHECK(cond, ...)            \
   do {                                   \
     if (!(cond)) {                       \

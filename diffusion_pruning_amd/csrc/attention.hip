@@ -552,6 +552,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const AttnK p) {
 extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream) {
   APTP_CHECK(p && p->q && p->k && p->v && p->o, "attention: null pointer");
   APTP_CHECK(p->B > 0 && p->heads > 0 && p->Lq > 0 && p->Lk > 0, "attention: bad extents");
+  if (p->io_f32) return aptp_attention_f32(p, stream);
   APTP_CHECK(p->q_stride_l % 8 == 0 && p->k_stride_l % 8 == 0 && p->v_stride_l % 8 == 0 && p->o_stride_l % 4 == 0, "attention: row strides must be multiples of 8 elements");
   APTP_CHECK(p->q_stride_b % 8 == 0 && p->k_stride_b % 8 == 0 && p->v_stride_b % 8 == 0 && p->o_stride_b % 4 == 0, "attention: batch strides must be multiples of 8 elements");
   APTP_CHECK(((uintptr_t)p->q % 16) == 0 && ((uintptr_t)p->k % 16) == 0 && ((uintptr_t)p->v % 16) == 0 && ((uintptr_t)p->o % 8) == 0, "attention: pointer alignment");

@@ -20,17 +20,29 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// Element type of the operands.  T = __bf16 is the product path.  T = float is the fp32 PARITY instantiation (SURVEY section 8:
+// "fp32 path kept for parity"; AptpConvGemmParams.io_f32): the same gather, tap walk, zero padding, K-slice bounds, split-K and
+// epilogue code on fp32 tensors and exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain), so addressing, border
+// classes and epilogue order are pinned on the GPU against the fp32 oracle at 1e-5 instead of bf16's 3e-3.  A 16-byte chunk is 8
+// bf16 or 4 fp32 values and an LDS row stays 128 bytes, so a K-step is 64 bf16 / 32 fp32 channels (the host passes ncc, nK and
+// Ktot in units of that step) and every index computation below is shared.  Never used by bench.py.
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> { static constexpr int EPC = 8, KS = 64; };
+template <> struct Elem<float> { static constexpr int EPC = 4, KS = 32; };
+
+template <int BM, int BN, int WM, int WN, typename T = __bf16>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int EPC = Elem<T>::EPC, KS = Elem<T>::KS, ES = (int)sizeof(T);   // elements per 16-byte chunk, per K-step; element size
+  constexpr bool F32 = sizeof(T) == 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MF = WTM / 16, NF = WTN / 16;
   constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
   static_assert(BM % 32 == 0 && BN % 32 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile shape");
 
-  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * (BM + BN) * BK];
-  __bf16* As = smem;
-  __bf16* Bs = smem + 2 * BM * BK;
+  __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * KS];
+  T* As = smem;
+  T* Bs = smem + 2 * BM * KS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -50,6 +62,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t x2src = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x2 ? p.x2 : p.x), 0, p.x2 ? p.x2_bytes : 0, 0x00020000);
+  // (p.x / p.w / p.x2 are byte addresses typed __bf16* in KParams whatever T is: all offsets below are in BYTES)
   constexpr unsigned OOB = 0x80000000u;
   const int chunk = tid & 7, rowbase = tid >> 3;
   int a_iy0[A_PASS], a_ix0[A_PASS], a_pix0[A_PASS], a_m[A_PASS];
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) {
     const int n = n0 + rowbase + 32 * i;
-    b_off[i] = n < p.N ? (unsigned)(((int64_t)n * p.Ktot + chunk * 8) * 2) : OOB;
+    b_off[i] = n < p.N ? (unsigned)(((int64_t)n * p.Ktot + chunk * EPC) * ES) : OOB;
   }
 
   // K-iteration state of the NEXT tile to load (l_ky == KH: the x2 segment after the filter taps)
@@ -89,12 +102,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   u32x4 ra[A_PASS], rb[B_PASS];
 
   auto load_tile = [&](bool pred) {
-    const int c = l_cc * BK + chunk * 8;
+    const int c = l_cc * KS + chunk * EPC;
     if (l_ky >= p.KH) {                       // wave-uniform: second operand, the output pixel itself
       const bool c_ok = pred && c < p.Cin2;
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
-        const unsigned off = ((unsigned)a_m[i] * (unsigned)p.ldx2 + (unsigned)c) * 2u;
+        const unsigned off = ((unsigned)a_m[i] * (unsigned)p.ldx2 + (unsigned)c) * (unsigned)ES;
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(x2src, (c_ok && a_m[i] >= 0) ? off : OOB, 0, 0);
       }
     } else {
@@ -104,11 +117,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
         int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
         const bool ok = c_ok && (unsigned)iy < (unsigned)p.HinE && (unsigned)ix < (unsigned)p.WinE && !(p.zins & (iy | ix));
         iy >>= p.ups; ix >>= p.ups;
-        const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * 2u;   // < 2^31 (checked on the host)
+        const unsigned off = ((unsigned)(a_pix0[i] + iy * p.Win + ix) * (unsigned)p.ldx + (unsigned)c) * (unsigned)ES;   // < 2^31 (checked on the host)
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ok ? off : OOB, 0, 0);
       }
     }
-    const unsigned koff = (unsigned)l_kt * (BK * 2);
+    const unsigned koff = (unsigned)l_kt * (KS * ES);
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, (b_off[i] == OOB || !pred) ? OOB : b_off[i] + koff, 0, 0);
@@ -126,13 +139,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
     for (int i = 0; i < A_PASS; ++i) {
       const int r = rowbase + 32 * i;
       const int sw = chunk ^ ((r >> 1) & 7);
-      *reinterpret_cast<u32x4*>(As + (buf * BM + r) * BK + sw * 8) = ra[i];
+      *reinterpret_cast<u32x4*>(As + (buf * BM + r) * KS + sw * EPC) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
       const int r = rowbase + 32 * i;
       const int sw = chunk ^ ((r >> 1) & 7);
-      *reinterpret_cast<u32x4*>(Bs + (buf * BN + r) * BK + sw * 8) = rb[i];
+      *reinterpret_cast<u32x4*>(Bs + (buf * BN + r) * KS + sw * EPC) = rb[i];
     }
   };
 
@@ -149,26 +162,55 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
   asm volatile("" : "+v"(abl_frag));
 #endif
   auto compute = [&](int buf) {
+    if constexpr (F32) {
+      // exact-fp32 MFMA 16x16x4: a lane supplies ONE value per operand, k = lane >> 4.  The two 16-byte chunks 2*fq and 2*fq+1
+      // of a row hold channels (2*fq + h)*4 + e of the 32-wide K-step: chunk h, element e feed the (h, e)-th of eight MFMAs,
+      // the same channel for both operands -- the sum over k is complete, in an order fixed by the layout.
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[MF], wf[NF];
+      for (int h = 0; h < 2; ++h) {
+        f32x4 af[MF], wf[NF];
 #pragma unroll
-      for (int i = 0; i < MF; ++i) {
-        const int r = wm * WTM + i * 16 + frow;
-        const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
-        af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * BM + r) * BK + sw * 8);
+        for (int i = 0; i < MF; ++i) {
+          const int r = wm * WTM + i * 16 + frow;
+          const int sw = (fq * 2 + h) ^ ((r >> 1) & 7);
+          af[i] = *reinterpret_cast<const f32x4*>(As + (buf * BM + r) * KS + sw * EPC);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int r = wn * WTN + j * 16 + frow;
+          const int sw = (fq * 2 + h) ^ ((r >> 1) & 7);
+          wf[j] = *reinterpret_cast<const f32x4*>(Bs + (buf * BN + r) * KS + sw * EPC);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], af[i][e], acc[i][j], 0, 0, 0);
       }
+    } else {
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int r = wn * WTN + j * 16 + frow;
-        const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
-        wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * BN + r) * BK + sw * 8);
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[MF], wf[NF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          const int r = wm * WTM + i * 16 + frow;
+          const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+          af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * BM + r) * KS + sw * EPC);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int r = wn * WTN + j * 16 + frow;
+          const int sw = (s * 4 + fq) ^ ((r >> 1) & 7);
+          wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * BN + r) * KS + sw * EPC);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+          for (int j = 0; j < NF; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -216,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KParams p) {
     }
     return;
   }
-  run_epilogue<4, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, wave, ln_mean, ln_rstd, smem);
+  run_epilogue<4, MF, NF, WTM, WTN, WN>(p, acc, m0, n0, tn, wm, wn, lane, wave, ln_mean, ln_rstd, reinterpret_cast<__bf16*>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1118,19 +1160,24 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   k.B = p->B; k.Hin = p->Hin; k.Win = p->Win; k.Cin = p->Cin; k.Hout = p->Hout; k.Wout = p->Wout;
   k.KH = p->KH; k.KW = p->KW; k.stride = p->stride; k.pad = p->pad; k.ups = sh; k.zins = p->ups == 2 ? 1 : 0;
   k.HinE = HinE; k.WinE = WinE;
-  k.x2 = (const __bf16*)p->x2; k.ldx2 = p->ldx2; k.Cin2 = p->x2 ? p->Cin2 : 0; k.ncc2 = p->x2 ? p->cin2_pad / BK : 0; k.x2_bytes = 0;
+  // fp32 parity instantiation (io_f32): 4-byte elements, a K-step is 32 channels (one 128-byte LDS row either way)
+  const int f32 = p->io_f32 ? 1 : 0, es = f32 ? 4 : 2, ks = f32 ? 32 : BK;
+  APTP_CHECK(!f32 || (p->out_f32 && !p->colstat_out && !p->gn_gamma && !p->prefetch),
+             "conv_gemm: io_f32 (fp32 parity path) writes fp32 and has no column statistics / fused GroupNorm / prefetch");
+  k.io_f32 = f32;
+  k.x2 = (const __bf16*)p->x2; k.ldx2 = p->ldx2; k.Cin2 = p->x2 ? p->Cin2 : 0; k.ncc2 = p->x2 ? p->cin2_pad / ks : 0; k.x2_bytes = 0;
   if (p->x2) {
     APTP_CHECK(p->Cin2 > 0 && p->Cin2 % 8 == 0 && p->cin2_pad % BK == 0 && p->cin2_pad >= p->Cin2 && p->cin2_pad < p->Cin2 + BK,
                "conv_gemm: x2 needs Cin2 (%d) a positive multiple of 8 and cin2_pad (%d) == ceil(Cin2/64)*64", p->Cin2, p->cin2_pad);
     APTP_CHECK(p->ldx2 % 8 == 0 && p->ldx2 >= p->Cin2 && ((uintptr_t)p->x2 % 16) == 0, "conv_gemm: x2 row stride / alignment");
     APTP_CHECK(p->stride == 1 && p->ups == 0 && p->Hout == p->Hin && p->Wout == p->Win,
                "conv_gemm: x2 (second operand read at the output pixel) needs a stride-1, same-size convolution");
-    const int64_t x2b = (((int64_t)p->B * p->Hout * p->Wout - 1) * p->ldx2 + p->Cin2) * 2;
+    const int64_t x2b = (((int64_t)p->B * p->Hout * p->Wout - 1) * p->ldx2 + p->Cin2) * es;
     APTP_CHECK(x2b < (1ll << 31), "conv_gemm: x2 larger than 2 GiB");
     k.x2_bytes = (int)x2b;
   }
-  k.w = (const __bf16*)p->w; k.N = p->N; k.ncc = p->cin_pad / BK; k.nK = p->KH * p->KW * k.ncc + k.ncc2;
-  k.Ktot = (int64_t)k.nK * BK;
+  k.w = (const __bf16*)p->w; k.N = p->N; k.ncc = p->cin_pad / ks; k.nK = p->KH * p->KW * k.ncc + k.ncc2;
+  k.Ktot = (int64_t)k.nK * ks;
   k.bias = p->bias; k.rowbias = p->rowbias; k.ld_rowbias = p->ld_rowbias;
   k.colgate = p->colgate; k.gate_group = p->gate_group; k.gate_B = p->gate_B;
   k.act = p->act; k.corr = p->corr; k.corr_B = p->corr_B;
@@ -1153,7 +1200,7 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   k.rstat_out = p->rowstat_out; k.rstat_slots = p->rowstat_slots;
   k.ln_stats = p->ln_stats; k.ln_slots = p->ln_slots; k.ln_colsum = p->ln_colsum; k.ln_eps = p->ln_eps;
   k.ln_invC = p->ln_C > 0 ? 1.0f / (float)p->ln_C : 0.f;
-  APTP_CHECK(!p->rowstat_out || (!geglu && !p->out_f32 && ((uintptr_t)p->rowstat_out % 16) == 0),
+  APTP_CHECK(!p->rowstat_out || (!geglu && (!p->out_f32 || f32) && ((uintptr_t)p->rowstat_out % 16) == 0),
              "conv_gemm: rowstat_out needs a bf16, non-GEGLU output and an 8-byte aligned buffer");
   APTP_CHECK(!p->ln_stats || (p->ln_colsum && p->ln_slots > 0 && p->ln_C > 0 && p->KH == 1 && p->KW == 1 &&
                               p->ln_slots % 2 == 0 && ((uintptr_t)p->ln_stats % 16) == 0 && ((uintptr_t)p->ln_colsum % 16) == 0),
@@ -1166,8 +1213,8 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
             (!p->residual || (p->ldres % 8 == 0 && ((uintptr_t)p->residual % 16) == 0)) &&
             (!p->depth || (p->lddin % 8 == 0 && ((uintptr_t)p->depth_in % 16) == 0));
   if (p->epilogue == 1) k.epi16 = 0;          // testing / tuning: force the accumulator-layout epilogue
-  const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * 2;
-  const int64_t wb = (int64_t)p->N * k.Ktot * 2;
+  const int64_t xb = (((int64_t)p->B * p->Hin * p->Win - 1) * p->ldx + p->Cin) * es;
+  const int64_t wb = (int64_t)p->N * k.Ktot * es;
   APTP_CHECK(xb < (1ll << 31) && wb < (1ll << 31), "conv_gemm: operand larger than 2 GiB");
   k.x_bytes = (int)xb; k.w_bytes = (int)wb;
   return APTP_OK;
@@ -1177,7 +1224,8 @@ template <int BM, int BN>
 void launch_tile(const KParams& k, hipStream_t s) {
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
   dim3 grid(tiles * k.split_k, 1, 1);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
+  if (k.io_f32) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2, 2, float>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, k);
 }
 
 template <int BM, int BN, int STAGES>
@@ -1302,6 +1350,10 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
   hipStream_t s = (hipStream_t)stream;
   int t = pick_tile(p, k.M);
   if (t < 0 || t >= kNumTiles) { aptp_set_error("conv_gemm: unknown tile %d", t); return APTP_EINVAL; }
+  if (k.io_f32 && t >= APTP_TILE_DMA_128x128) {
+    aptp_set_error("conv_gemm: io_f32 (fp32 parity path) runs on the register-staged tiles 1..6 only (got tile %d)", t);
+    return APTP_EINVAL;
+  }
   if (t >= APTP_TILE_DMA_128x128 && !is_sk_tile(t) && (p->cin_pad * 2 > 8064 || (p->x2 && p->cin2_pad * 2 > 8064))) {
     // the LDS-DMA variants stream padding lanes from an 8 KiB zero page that must cover one channel row
     aptp_set_error("conv_gemm: LDS-DMA tiles need Cin <= 4032 (got cin_pad %d)", p->cin_pad);

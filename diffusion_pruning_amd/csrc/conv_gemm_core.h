@@ -67,6 +67,7 @@ struct KParams {
   int* counters;            // in-kernel split-K: one arrival counter per output tile (zero on entry, left zero)
   float* cstat_out; int cstat_ld;   // per-(row block, channel) (sum, sumsq) of the stored outputs: GroupNorm statistics
   int epi16;                // 1: bf16 output (and residual / depth_in) rows are 16-byte aligned -> coalesced epilogue
+  int io_f32;               // 1: fp32 parity instantiation (AptpConvGemmParams.io_f32): x, w, x2, residual, depth_in, y are fp32
   float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
   const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
   const float* gn_gamma; const float* gn_beta; int gn_groups, gn_C, gn_silu; float gn_eps;   // reduce launch applies a GroupNorm
@@ -202,17 +203,30 @@ __device__ __forceinline__ void epilogue_quad(const KParams& p, int m, const Row
   epilogue_pre<GEGLU>(p, rc, n, cv, h, g, v);
   const int c = GEGLU ? ((n >> 5) * 16 + (n & 15)) : n;   // logical output column of element 0
   if (p.residual && !(APTP_ABLATE & 64)) {
-    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldres + c);
-    union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
+    if (p.io_f32) {           // (wave-uniform) fp32 parity instantiation: residual / depth_in / y are fp32 tensors
+      const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + (int64_t)m * p.ldres + c);
+      v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    } else {
+      const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldres + c);
+      union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += (float)ru.e[r];
+      for (int r = 0; r < 4; ++r) v[r] += (float)ru.e[r];
+    }
   }
   if (p.depth && !(APTP_ABLATE & 64)) {
     const float d = p.depth[b % p.depth_B];
-    const uint2 rr = *reinterpret_cast<const uint2*>(p.depth_in + (int64_t)m * p.lddin + c);
-    union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
+    float din[4];
+    if (p.io_f32) {
+      const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.depth_in) + (int64_t)m * p.lddin + c);
+      din[0] = rr.x; din[1] = rr.y; din[2] = rr.z; din[3] = rr.w;
+    } else {
+      const uint2 rr = *reinterpret_cast<const uint2*>(p.depth_in + (int64_t)m * p.lddin + c);
+      union { uint2 u; __bf16 e[4]; } ru; ru.u = rr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (1.0f - d) * (float)ru.e[r] + d * v[r];
+      for (int r = 0; r < 4; ++r) din[r] = (float)ru.e[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (1.0f - d) * din[r] + d * v[r];
   }
 #if APTP_ABLATE & 32
   asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
@@ -221,6 +235,10 @@ __device__ __forceinline__ void epilogue_quad(const KParams& p, int m, const Row
   if (p.out_f32) {
     float4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.ldy + c) = o;
+    if (p.io_f32 && p.rstat_out) {          // fp32 storage: the statistics are those of the stored values themselves
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st[0] += v[r]; st[1] += v[r] * v[r]; }
+    }
   } else {
     union { uint2 u; __bf16 e[4]; } o;
     o.u.x = pack_bf16x2(v[0], v[1]); o.u.y = pack_bf16x2(v[2], v[3]);

@@ -609,6 +609,7 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   APTP_CHECK(p && p->x && p->y && p->gamma && p->beta && p->workspace, "groupnorm: null pointer");
   APTP_CHECK(p->B > 0 && p->HW > 0 && p->C > 0 && p->groups > 0 && p->groups <= 32, "groupnorm: bad extents (groups <= 32)");
   APTP_CHECK(p->C % p->groups == 0, "groupnorm: C (%d) not divisible by groups (%d)", p->C, p->groups);
+  if (p->io_f32) return aptp_groupnorm_f32(p, stream);
   const int CO = (p->C + 7) / 8;
   APTP_CHECK(p->ldx % 8 == 0 && p->ldy % 8 == 0 && p->ldx >= CO * 8 && p->ldy >= CO * 8, "groupnorm: ld must be a multiple of 8 and >= roundup8(C)");
   APTP_CHECK(((uintptr_t)p->x % 16) == 0 && ((uintptr_t)p->y % 16) == 0, "groupnorm: pointer alignment");
@@ -703,6 +704,10 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
 
 extern "C" int aptp_layernorm(const AptpLayerNormParams* p, aptp_stream_t stream) {
   APTP_CHECK(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
+  if (p->io_f32) {
+    APTP_CHECK(p->rows > 0 && p->C > 0 && p->ldx >= p->C && p->ldy >= p->C, "layernorm(io_f32): bad extents");
+    return aptp_layernorm_f32(p, stream);
+  }
   APTP_CHECK(p->rows > 0 && p->C > 0 && p->C % 8 == 0 && p->C <= 2048, "layernorm: C (%d) must be a multiple of 8, <= 2048", p->C);
   APTP_CHECK(p->ldx % 8 == 0 && p->ldy % 8 == 0 && p->ldx >= p->C && p->ldy >= p->C, "layernorm: ld");
   APTP_CHECK(((uintptr_t)p->x % 16) == 0 && ((uintptr_t)p->y % 16) == 0 && ((uintptr_t)p->gamma % 16) == 0 && ((uintptr_t)p->beta % 16) == 0, "layernorm: pointer alignment");

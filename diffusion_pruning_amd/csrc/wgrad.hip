@@ -1,5 +1,6 @@
-// Weight gradient of a stride-1 "same" convolution (3x3 or 1x1 / linear) for the expert fine-tune step (SURVEY a20,
-// trainer.py:1616 loss.backward through F.conv2d / F.linear): dW[n][tap][c] = sum_m dy[m][n] * x[pix(m, tap)][c].
+// Weight gradient of a "same" convolution (3x3 or 1x1 / linear; 3x3 also with stride 2 -- the down-samplers -- or a folded
+// nearest-x2 up-sample -- the up-samplers) for the expert fine-tune step (trainer.py:1616 loss.backward through
+// F.conv2d / F.linear): dW[n][tap][c] = sum_m dy[m][n] * x[pix(m, tap)][c].
 //
 // The contraction runs over PIXELS, and both operands are stored pixel-major (channels contiguous), so the MFMA's K
 // dimension is the strided one.  gfx950's transposed LDS read (ds_read_b64_tr_b16: a 4-row x 16-column block delivered
@@ -15,6 +16,14 @@
 // packed-weight order [n][tap][c].  Global loads of step s+1 are in flight during the MFMAs of step s (register staging,
 // two LDS buffers, one barrier per step).  The pixel range is split over `split_m` workgroups (fp32 slabs, summed by the
 // caller in a fixed order: deterministic).
+//
+// Resampling convolutions (AptpWgradParams.stride / ups; H, W are always the OUTPUT map, the one dy lives on).  Stride 2:
+// the halo of a step's R x Wt output pixels is (2R+1) x (2Wt+1) INPUT pixels (up to 195 rows: a template instantiation with a
+// larger x image), output pixel (r, c) sits at halo (2r, 2c), so its tap (ky, kx) is halo row (2r + ky) * hw2 + 2c + kx and the
+// second 4-pixel block of a fragment lies 8 halo rows on instead of 4.  Nearest-x2: the halo lives on the up-sampled grid
+// ((R+2) x (Wt+2), exactly the stride-1 geometry) and each halo entry is FETCHED from input pixel (iy >> 1, ix >> 1), zero
+// outside the up-sampled extent -- the gather of the forward kernel, nothing materialised.  (Round 2 ran these six layers as
+// GEMMs on transposed torch copies, or as four stride-1 calls on parity planes that compute 36 tap results to use 9.)
 #include "aptp_common.h"
 #include <stdlib.h>
 
@@ -28,7 +37,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct WgK {
   const __bf16* x; int64_t ldx; const __bf16* dy; int64_t lddy; float* dw;
   int B, H, W, C, N, M, HW, split, nsteps, tiles_n, tiles_c;
-  int Wt, R, hw2;      // halo geometry (3x3): tile width, rows per step, Wt + 2
+  int Wt, R, hw2;      // halo geometry (3x3): tile width, rows per step, halo width (Wt + 2; stride 2: 2 Wt + 1)
+  int Hin, Win, ups;   // input map extent; ups = 1: halo coordinates are on the nearest-x2 up-sampled grid
   int ldw;             // row length of dw's c dimension
   float* db;           // optional [split][N]: column sums of dy over the slice (written by the workgroups of c-block 0)
   int64_t slab_stride, db_stride;
@@ -37,6 +47,7 @@ struct WgK {
 #define APTP_WGRAD_SUB_DEFAULT 2      // measured on the fine-tune step: 38.3 / 37.7 / 38.0 ms with 1 / 2 / 4
 constexpr int PITCH = 72;          // bf16 elements per LDS row (64 + 8: spreads the 4-row transposed blocks over the banks)
 constexpr int XROWS = 104;         // halo rows per buffer: (R+2) * (Wt+2) <= 102
+constexpr int XROWS_S2 = 200;      // stride 2: (2R+1) * (2Wt+1) <= 195
 
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* lds_row_q_col_4p, int plus4_rows_elems) {
   // two 4-row x 16-column transposed blocks -> the 8 consecutive k of one MFMA operand lane
@@ -50,12 +61,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* lds_row_q_col_4p, int pl
 
 // SUB: 32-pixel sub-steps per barrier.  The 3x3 form stages one halo per 32 pixels (SUB = 1); a 1x1 / linear layer has no halo
 // and only 4 MFMAs per wave and sub-step, so it takes 64 pixels per barrier (SUB = 2; 4 fits too -- 74 KB of LDS -- and measures the same).
-template <int TAPS, int SUB>
+template <int TAPS, int SUB, int STRIDE = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   static_assert(TAPS == 1 || SUB == 1, "sub-steps only without a halo");
+  static_assert(STRIDE == 1 || TAPS == 9, "stride 2: the 3x3 down-samplers");
+  constexpr int XR = STRIDE == 2 ? XROWS_S2 : XROWS;
   __shared__ __attribute__((aligned(16))) __bf16 dys[2][32 * SUB * PITCH];
-  __shared__ __attribute__((aligned(16))) __bf16 xs[2][(TAPS == 9 ? XROWS : 32 * SUB) * PITCH];
-  constexpr int XCH = TAPS == 9 ? 4 : SUB;         // 16-byte x chunks per thread and step (<= 102 * 8 / 256)
+  __shared__ __attribute__((aligned(16))) __bf16 xs[2][(TAPS == 9 ? XR : 32 * SUB) * PITCH];
+  constexpr int XCH = TAPS == 9 ? (XR * 8 + 255) / 256 : SUB;         // 16-byte x chunks per thread and step
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wc = wave & 1;
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   for (int e = 0; e < 8; ++e) dbacc[e] = 0.f;
   u32x4 rdy[SUB], rx[XCH];
   const int dj = tid >> 3, dch = tid & 7;          // dy tile: row (pixel of the sub-step), 16-byte chunk
-  const int xrows = TAPS == 9 ? (p.R + 2) * p.hw2 : 32;
+  const int xrows = TAPS == 9 ? (STRIDE * (p.R - 1) + 3) * p.hw2 : 32;
   auto load_step = [&](int step) {
     const int m0 = step * 32 * SUB;
 #pragma unroll
@@ -92,9 +105,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
         rx[i] = (u32x4){0u, 0u, 0u, 0u};
         if (hr < xrows) {
           const int hy = hr / p.hw2, hx = hr - hy * p.hw2;
-          const int iy = y0 - 1 + hy, ix = x0 - 1 + hx, c = c0 + ch * 8;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.C)
-            rx[i] = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)(b * p.H + iy) * p.W + ix) * p.ldx + c);
+          // halo coordinates on the (up-sampled) input grid; with ups the source pixel is (iy >> 1, ix >> 1)
+          const int iy = STRIDE * y0 - 1 + hy, ix = STRIDE * x0 - 1 + hx, c = c0 + ch * 8;
+          if ((unsigned)iy < (unsigned)(p.Hin << p.ups) && (unsigned)ix < (unsigned)(p.Win << p.ups) && c < p.C)
+            rx[i] = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)(b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) * p.ldx + c);
         }
       }
     } else {
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const int j = 8 * g + q;                                   // pixel of the step this lane addresses (and j + 4)
   int xrow = j;                                              // its row in the x image for tap (0, 0)
-  if (TAPS == 9) xrow = (j / p.Wt) * p.hw2 + (j % p.Wt);    // (halo coordinates of the pixel's top-left neighbour)
+  if (TAPS == 9) xrow = STRIDE * ((j / p.Wt) * p.hw2 + (j % p.Wt));    // (halo coordinates of the pixel's top-left neighbour)
   const int x_off = xrow * PITCH + wc * 32 + 4 * pp;         // + cf*16 + tap shift * PITCH
   const int d_off = j * PITCH + wn * 32 + 4 * pp;            // + nf*16
 
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
           const int shift = TAPS == 9 ? ((t / 3) * p.hw2 + (t % 3)) * PITCH : 0;
 #pragma unroll
           for (int cf = 0; cf < 2; ++cf) {
-            const bf16x8 xf = tr_frag(&xs[buf][sub_off + x_off + shift + cf * 16], 4 * PITCH);
+            const bf16x8 xf = tr_frag(&xs[buf][sub_off + x_off + shift + cf * 16], 4 * STRIDE * PITCH);
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
               acc[t][cf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, dfr[nf], acc[t][cf][nf], 0, 0, 0);
@@ -215,6 +229,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
 extern "C" int aptp_conv_wgrad_supported(const AptpWgradParams* p) {
   if (!p || (p->KH != 1 && p->KH != 3) || p->KH != p->KW) return 0;
   if (p->C % 8 || p->N % 8 || p->ldx % 8 || p->lddy % 8) return 0;
+  if (p->stride != 0 && p->stride != 1 && p->stride != 2) return 0;
+  if ((p->stride == 2 || p->ups) && (p->KH != 3 || (p->stride == 2 && p->ups) || (p->ups != 0 && p->ups != 1))) return 0;
+  if (p->ups && ((p->H | p->W) & 1)) return 0;
   if (p->KH == 3) {
     const int W = p->W, HW = p->H * p->W;
     if (HW % 32) return 0;
@@ -239,6 +256,10 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   WgK k;
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dw = p->dw;
   k.B = p->B; k.H = p->H; k.W = p->W; k.C = p->C; k.N = p->N; k.HW = p->H * p->W; k.M = p->B * k.HW;
+  const int stride = p->stride == 2 ? 2 : 1;
+  k.ups = p->ups ? 1 : 0;
+  k.Hin = stride == 2 ? 2 * p->H : (k.ups ? p->H / 2 : p->H);
+  k.Win = stride == 2 ? 2 * p->W : (k.ups ? p->W / 2 : p->W);
   // sub-steps per barrier of the 1x1 form (APTP_WGRAD_SUB = 1 / 2 / 4 for A/B timing)
   static const int sub_env = [] { const char* e = getenv("APTP_WGRAD_SUB"); return e ? atoi(e) : 0; }();
   const int SUB1 = (sub_env == 1 || sub_env == 2 || sub_env == 4) ? sub_env : APTP_WGRAD_SUB_DEFAULT;
@@ -252,11 +273,12 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   k.split = p->split_m;                 // (a slice without a barrier step of its own writes zeros: the caller folds split_m slabs)
   APTP_CHECK(p->split_m <= (k.M + 31) / 32, "conv_wgrad: split_m %d exceeds the %d 32-pixel steps", p->split_m, (k.M + 31) / 32);
   k.tiles_n = (p->N + 63) / 64; k.tiles_c = (p->C + 63) / 64;
-  k.Wt = p->W < 32 ? p->W : 32; k.R = p->W < 32 ? 32 / p->W : 1; k.hw2 = k.Wt + 2;
-  APTP_CHECK(p->KH == 1 || (k.R + 2) * k.hw2 <= XROWS, "conv_wgrad: halo does not fit");
+  k.Wt = p->W < 32 ? p->W : 32; k.R = p->W < 32 ? 32 / p->W : 1; k.hw2 = stride * (k.Wt - 1) + 3;
+  APTP_CHECK(p->KH == 1 || (stride * (k.R - 1) + 3) * k.hw2 <= (stride == 2 ? XROWS_S2 : XROWS), "conv_wgrad: halo does not fit");
   const int64_t nblk = (int64_t)k.tiles_n * k.tiles_c * k.split;
   APTP_CHECK(nblk < (1LL << 31), "conv_wgrad: grid too large");
-  if (p->KH == 3) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  if (p->KH == 3 && stride == 2) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1, 2>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  else if (p->KH == 3) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
   else if (SUB1 == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
   else if (SUB1 == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
   else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);

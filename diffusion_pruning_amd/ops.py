@@ -38,8 +38,10 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _check_act(x: torch.Tensor, name: str):
-    if x.dtype != torch.bfloat16 or x.dim() != 4 or x.stride(3) != 1 or not x.is_cuda:
-        raise ValueError(f"{name}: expected a CUDA bf16 [B,H,W,C] tensor with contiguous channels, got "
+    # bf16 is the product's activation format; fp32 tensors take the fp32 PARITY instantiations of the kernels (io_f32 of the
+    # parameter blocks: same code paths on exact-fp32 arithmetic, tests/test_fp32_parity_gpu.py; never benchmarked)
+    if x.dtype not in (torch.bfloat16, torch.float32) or x.dim() != 4 or x.stride(3) != 1 or not x.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA bf16 (or, parity path, fp32) [B,H,W,C] tensor with contiguous channels, got "
                          f"{x.dtype} {tuple(x.shape)} strides {x.stride()}")
     B, H, W, C = x.shape
     ld = _ld(x)
@@ -490,6 +492,14 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if pw.geglu:
         act = ACT_GEGLU
     nout = pw.N // 2 if act == ACT_GEGLU else pw.N
+    f32 = x.dtype == torch.float32                # fp32 parity instantiation: every tensor operand fp32, tiles 1..6, no tables
+    gn_f32 = None
+    if f32:
+        if pw.w.dtype != torch.float32:
+            raise ValueError("conv_gemm: fp32 activations need weights packed under ops.ACT_DTYPE = torch.float32")
+        out_f32, colstats, prefetch, gn_f32, gn = True, False, False, gn, None
+        if tile not in (0, 1, 2, 3, 4, 5, 6):
+            raise ValueError("conv_gemm: the fp32 parity path runs on the register-staged tiles 1..6")
     if out is None:
         out = torch.empty(B, Hout, Wout, nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     else:
@@ -538,6 +548,11 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.tile = tile
     p.order = order
     p.epilogue = EPILOGUE
+    p.io_f32 = int(f32)
+    if f32:
+        for t_, nm in ((x2, "x2"), (residual, "residual"), (depth_in, "depth_in")):
+            if t_ is not None and t_.dtype != torch.float32:
+                raise ValueError(f"conv_gemm: fp32 parity path: {nm} must be fp32 too")
     if prefetch is False:             # the "weights" of this launch are a temporary (conv_wgrad): not part of any plan
         prefetch = None
     elif PREFETCH_WEIGHTS and prefetch is None:
@@ -549,7 +564,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     p.split_k = 1
     in_kernel = None                 # split-K form: tuned per shape; untuned shapes combine in-kernel up to 4 slices
     explicit_split = split_k is not None
-    if split_k is None and tile == 0:
+    if split_k is None and tile == 0 and not f32:
         tuned = tuning_lookup(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2)
         if tuned is not None and tuned["tile"] >= 7 and max(pw.cin_pad, pw.cin2_pad) > (32704 if tuned["tile"] >= SK_TILE_FIRST else 4032):
             tuned = None                   # the LDS-DMA tiles address at most 4032 channels per tap (a neighbour's tile may be one)
@@ -558,7 +573,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             in_kernel = bool(tuned.get("in_kernel", 0))
             if order == 0:
                 p.order = tuned.get("order", 1)     # tables tuned before the XCD-aware orders existed mean the legacy order
-    if split_k is None and tile == 0 and p.tile == 0 and SK_AUTO:
+    if split_k is None and tile == 0 and p.tile == 0 and SK_AUTO and not f32:
         # no table entry: contractions with >= SK_AUTO_MIN_OUTPUTS outputs (a chip-filling number of 256 x 160 macro-tiles) and
         # a long K take the persistent stream-K macro-tiles -- measured 1.28-1.42x the best per-tile launch on such shapes
         # (tools/bench_sk.py: 16384 x 1280 x 11520 at 1,093 TFLOP/s; 8192^3 at 995 against 744) -- and nothing below that
@@ -635,6 +650,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * (pw.KH * pw.KW * pw.Cin + pw.Cin2),
                            "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats, x2, gn)})
+    if f32 and gn_f32 is not None:
+        gn = gn_f32
     if gn is not None and not gn_fused:
         gamma, beta, groups, eps_, silu_, Cn = gn
         return groupnorm(out, gamma, beta, groups, eps_, silu_, C=Cn)
@@ -666,11 +683,18 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
     assert Cp == round_up(C, 8), f"groupnorm: tensor width {Cp} != roundup8({C})"
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
     if out is None:
-        out = torch.empty(B, H, W, Cp, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(B, H, W, Cp, dtype=x.dtype, device=x.device)
     p = GroupNormParams()
     p.x, p.ldx, p.y, p.ldy = x.data_ptr(), _ld(x), out.data_ptr(), _ld(out)
     p.B, p.HW, p.C, p.groups = B, H * W, C, groups
     p.gamma, p.beta, p.eps, p.silu = gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
+    if x.dtype == torch.float32:          # fp32 parity path (csrc/parity_f32.hip): three plain launches, no producer statistics
+        assert out.dtype == torch.float32 and not keep_stats
+        p.io_f32, p.variant = 1, 1
+        ws = _workspace(lib.aptp_groupnorm_workspace_bytes(ctypes.byref(p)), x.device)
+        p.workspace = ws.data_ptr()
+        _lib.check(lib.aptp_groupnorm(ctypes.byref(p), _stream()), "aptp_groupnorm(io_f32)")
+        return out
     if keep_stats:
         # [B, nchunk + 1, G, 2]: the partials the backward needs, plus the finalised (mean, rstd) slot the kernels append
         nch = lib.aptp_groupnorm_nchunk(H * W)
@@ -703,12 +727,13 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     """LayerNorm over the last dim of a bf16 [B, L, C] tensor."""
     lib = _lib.load()
     B, L, C = x.shape
-    assert x.dtype == torch.bfloat16 and x.stride(2) == 1 and x.is_cuda
+    assert x.dtype in (torch.bfloat16, torch.float32) and x.stride(2) == 1 and x.is_cuda
     ld = x.stride(1) if L > 1 else max(x.stride(1), C)
     assert B == 1 or L == 1 or x.stride(0) == L * ld
     if out is None:
-        out = torch.empty(B, L, C, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(B, L, C, dtype=x.dtype, device=x.device)
     p = LayerNormParams()
+    p.io_f32 = int(x.dtype == torch.float32)      # fp32 parity path (csrc/parity_f32.hip)
     p.x, p.ldx, p.y, p.ldy = x.data_ptr(), ld, out.data_ptr(), out.stride(1) if L > 1 else C
     p.rows, p.C = B * L, C
     p.gamma, p.beta, p.eps = gamma.data_ptr(), beta.data_ptr(), eps
@@ -724,10 +749,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     B, Lq = q.shape[0], q.shape[1]
     Lk = k.shape[1]
     for t in (q, k, v):
-        assert t.dtype == torch.bfloat16 and t.stride(2) == 1 and t.shape[2] == heads * 64 and t.is_cuda
+        assert t.dtype == q.dtype and t.dtype in (torch.bfloat16, torch.float32) and t.stride(2) == 1 and t.shape[2] == heads * 64 and t.is_cuda
     if out is None:
-        out = torch.empty(B, Lq, heads * 64, dtype=torch.bfloat16, device=q.device)
+        out = torch.empty(B, Lq, heads * 64, dtype=q.dtype, device=q.device)
     p = AttentionParams()
+    p.io_f32 = int(q.dtype == torch.float32)      # fp32 parity path (csrc/parity_f32.hip)
     p.q, p.q_stride_b, p.q_stride_l = q.data_ptr(), q.stride(0), q.stride(1)
     p.k, p.k_stride_b, p.k_stride_l = k.data_ptr(), k.stride(0), k.stride(1)
     p.v, p.v_stride_b, p.v_stride_l = v.data_ptr(), v.stride(0), v.stride(1)
@@ -1203,19 +1229,21 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, scale: Optional
 WGRAD_KERNEL = os.environ.get("APTP_WGRAD_KERNEL", "1") != "0"
 WGRAD_SPLIT_TARGET = int(os.environ.get("APTP_WGRAD_SPLIT_TARGET", "0"))
 WGRAD_PARITY = True       # _wgrad_parity where its rule selects it (False: copies + GEMM for every resampling convolution)
+WGRAD_RESAMPLE = os.environ.get("APTP_WGRAD_RESAMPLE", "1") != "0"    # stride-2 / nearest-x2 3x3 layers through aptp_conv_wgrad itself
 
 
 def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: Optional[int] = None,
-                  out: Optional[torch.Tensor] = None, want_db: bool = False):
+                  out: Optional[torch.Tensor] = None, want_db: bool = False, stride: int = 1, ups: int = 0):
     """x [B,H,W,C], dy [B,H,W,N] (bf16, channels contiguous, uniform pixel stride) -> fp32 [N, KH*KW, C] or None when
     the geometry is not handled by aptp_conv_wgrad.  out: an fp32 [N, KH*KW, ld >= C] buffer (a packed-layout gradient) that
     receives the result in its first C columns (the rest is left alone); returned instead of a fresh tensor."""
     lib = _lib.load()
-    B, H, W, C = x.shape
-    N = dy.shape[3]
+    B, C = x.shape[0], x.shape[3]
+    H, W, N = dy.shape[1], dy.shape[2], dy.shape[3]           # (the OUTPUT map: the pixels the contraction runs over)
     p = WgradParams()
     p.x, p.ldx, p.dy, p.lddy = x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy)
     p.B, p.H, p.W, p.C, p.N, p.KH, p.KW = B, H, W, C, N, KH, KW
+    p.stride, p.ups = stride, ups
     if x.data_ptr() % 16 or dy.data_ptr() % 16 or not lib.aptp_conv_wgrad_supported(ctypes.byref(p)):
         return None
     _check_act(x, "conv_wgrad x")
@@ -1349,6 +1377,14 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     C, N = x.shape[-1], dy.shape[-1]
     if WGRAD_KERNEL and stride == 1 and ups == 0 and KH == KW and pad == KH // 2 and x.shape[:3] == dy.shape[:3]:
         g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db)
+        if g is not None:
+            return g
+    # the six resampling convolutions of the U-Net (3x3: stride-2 down-samplers, nearest-x2 up-samplers): the same kernel with
+    # a strided / up-sampled halo (csrc/wgrad.hip)
+    if (WGRAD_KERNEL and WGRAD_RESAMPLE and KH == 3 and KW == 3 and pad == 1 and x.dim() == 4 and x.shape[0] == dy.shape[0]
+            and ((stride == 2 and ups == 0 and x.shape[1] == 2 * dy.shape[1] and x.shape[2] == 2 * dy.shape[2])
+                 or (stride == 1 and ups == 1 and dy.shape[1] == 2 * x.shape[1] and dy.shape[2] == 2 * x.shape[2]))):
+        g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db, stride=stride, ups=ups)
         if g is not None:
             return g
     # resampling convolutions: the parity split only pays where the fine grid is large and the weight small -- it runs the

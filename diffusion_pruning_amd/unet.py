@@ -1720,7 +1720,8 @@ class UNet2DConditionModelGated(nn.Module):
         elif timesteps.dim() == 0:
             timesteps = timesteps[None].to(dev)
         timesteps = timesteps.to(dev).expand(B)
-        fused_io = sample.is_cuda and sample.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled()
+        fused_io = sample.is_cuda and sample.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled() \
+            and ops.ACT_DTYPE == torch.bfloat16          # (the one-launch prologue / epilogue stage bf16; the fp32 parity path does not)
         if fused_io:
             # one launch: sinusoid [cos|sin] as bf16 + the channel-padded channels-last copy of the sample
             x, t_emb = ops.unet_prologue(sample, timesteps, misc["freqs"], misc["cin_pad"])

@@ -141,6 +141,12 @@ typedef struct {
   const float* gn_beta;
   int32_t gn_groups, gn_C, gn_silu;
   float gn_eps;
+  /* fp32 PARITY instantiation (never benchmarked): x, w (packed fp32 [N][KH*KW][Cin_pad]), x2, residual, depth_in and y are fp32
+   * tensors (out_f32 must be 1; row strides in elements as always), the contraction runs on exact-fp32 MFMAs
+   * (v_mfma_f32_16x16x4_f32) through the SAME gather / tap walk / zero padding / split-K / epilogue code as the bf16
+   * register-staged kernel (tiles 1..6 only).  Pins addressing and epilogue order on the GPU against the fp32 oracle at 1e-5
+   * per op; the reference computes in fp32 (configs/pruning/sd-2-1_cc3m.yaml:79). */
+  int32_t io_f32;
 } AptpConvGemmParams;
 
 enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TILE_64x128 = 3, APTP_TILE_64x160 = 4,
@@ -237,6 +243,9 @@ typedef struct {
    * (segment 0 = channels [0, C0), segment 1 = [C0, C)).  The statistics pass over x is skipped: a (groups x B)-workgroup
    * finalise from the partials, then the apply pass (two launches, x read once). */
   AptpGroupNormColStats colstats[2];
+  /* fp32 PARITY path (csrc/parity_f32.hip; never benchmarked): x and y are fp32, three plain launches with the product's
+   * statistics layout and variance formula; no producer statistics, no fused finalize */
+  int32_t io_f32;
 } AptpGroupNormParams;
 
 int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream);
@@ -254,6 +263,7 @@ typedef struct {
   int32_t rows, C;
   const float* gamma; const float* beta;
   float eps;
+  int32_t io_f32;   /* fp32 PARITY path: x and y are fp32 (csrc/parity_f32.hip) */
 } AptpLayerNormParams;
 
 int aptp_layernorm(const AptpLayerNormParams* p, aptp_stream_t stream);
@@ -278,6 +288,7 @@ typedef struct {
                     * 4 = force two lock-step groups with double-buffered K/V (one barrier per key tile; auto from 32 key
                     * tiles); 5 = force the 4-wave kernel (one group).  An explicit variant overrides the occupancy rule
                     * that otherwise chooses between one and two groups */
+  int32_t io_f32;  /* fp32 PARITY path: q, k, v, o are fp32 (strides in elements), no lse (csrc/parity_f32.hip) */
 } AptpAttentionParams;
 
 int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream);
@@ -407,6 +418,10 @@ typedef struct {
                                       workgroups of input-channel block 0 sum the dy tiles they stage anyway) */
   int64_t slab_stride;             /* elements between consecutive slices of dw; 0 = N*KH*KW*ld_dw */
   int64_t db_stride;               /* elements between consecutive slices of db; 0 = N (both non-zero: db rows appended to dw's slabs) */
+  /* resampling 3x3 convolutions (Downsample2D / Upsample2D of the U-Net).  H, W above are always the OUTPUT map (the one dy
+   * lives on).  stride 2 (0 and 1 both mean 1): x is [B, 2H, 2W, C], pad 1.  ups 1: the convolution reads the nearest-x2
+   * up-sampled input: x is [B, H/2, W/2, C].  Not both. */
+  int32_t stride, ups;
 } AptpWgradParams;
 int aptp_conv_wgrad_supported(const AptpWgradParams* p);
 int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p);

@@ -282,6 +282,43 @@ def test_conv_wgrad_kernel(ops, cuda, case, split):
 
 
 @pytest.mark.parametrize("kind", ["stride2", "ups"])
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 16, 16, 72, 136), (1, 64, 64, 64, 64), (2, 32, 32, 128, 72), (3, 16, 16, 8, 8)])
+def test_conv_wgrad_kernel_on_resampling_convs(ops, cuda, kind, B, H, W, C, N):
+    """the six down / up-sampler convolutions through aptp_conv_wgrad itself (strided / up-sampled halo: output maps 32, 16 and 8
+    pixels wide, i.e. one, two and four image rows per 32-pixel step): weight gradient vs PyTorch's, bias gradient as a
+    by-product, in-place into a padded packed-layout buffer, deterministic; and equal to the copies + GEMM fallback"""
+    g = torch.Generator().manual_seed(17 + H + C)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = torch.zeros(N, C, 3, 3, requires_grad=True)
+    if kind == "stride2":
+        dy = torch.randn(B, N, H // 2, W // 2, generator=g).bfloat16().float()
+        F.conv2d(x, w, None, stride=2, padding=1).backward(dy)
+        args = dict(stride=2, pad=1, ups=0)
+    else:
+        dy = torch.randn(B, N, 2 * H, 2 * W, generator=g).bfloat16().float()
+        F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, stride=1, padding=1).backward(dy)
+        args = dict(stride=1, pad=1, ups=1)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(N, 9, C)
+    xd, dyd = nhwc(x).to(cuda).bfloat16(), nhwc(dy).to(cuda).bfloat16()
+    direct = ops._wgrad_direct(xd, dyd, 3, 3, stride=args["stride"], ups=args["ups"])
+    assert direct is not None, "must take the kernel path"
+    got, db = ops.conv_wgrad(xd, dyd, 3, 3, want_db=True, **args)
+    assert rel_l2(got.cpu(), ref) <= 2e-3 and rel_l2(db.cpu(), dy.sum(dim=(0, 2, 3))) <= 1e-5
+    assert torch.equal(got, direct)                                       # deterministic, same path
+    one = ops._wgrad_direct(xd, dyd, 3, 3, split_m=1, stride=args["stride"], ups=args["ups"])
+    assert rel_l2(one.cpu(), ref) <= 2e-3
+    out = torch.full((N, 9, C + 8), -1.0, device=cuda)
+    ops.conv_wgrad(xd, dyd, 3, 3, out=out, **args)
+    assert torch.equal(out[:, :, :C], got) and bool((out[:, :, C:] == -1).all())
+    ops.WGRAD_KERNEL = False
+    try:
+        old = ops.conv_wgrad(xd, dyd, 3, 3, **args)
+    finally:
+        ops.WGRAD_KERNEL = True
+    assert rel_l2(got.cpu(), old.cpu()) <= 2e-3
+
+
+@pytest.mark.parametrize("kind", ["stride2", "ups"])
 def test_conv_wgrad_of_resampling_convs_by_parity_split(ops, cuda, kind):
     """the six down/up-sampler convolutions: weight gradient through four stride-1 correlations on the parity planes
     (ops._wgrad_parity) vs PyTorch's, and vs the GEMM-on-transposed-copies fallback; bias gradient as a by-product"""

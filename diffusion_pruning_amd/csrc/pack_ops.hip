@@ -10,16 +10,16 @@
 
 namespace {
 
-struct FoldK { const float* in; float* out; int R, n_rows, C, ld_out; float* tail_out; int rows1; };
+struct FoldK { const float* in; float* out; int R, n_rows, C, ld_out; float* tail_out; int rows1; int pair_split; int tail_n; };
 
 // block = 32 column quads x 8 row slices: slice s sums rows s, s+8, ... (independent 16-byte loads in flight), the slices are
 // folded 0..7 through LDS: the order is fixed, the result does not depend on scheduling
-__global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) {
+__device__ __forceinline__ void fold_rows_block(const FoldK& p, int64_t blk) {
   __shared__ float4 red[8][32];
   const int64_t total = (int64_t)p.n_rows * p.C;
   const int cq = threadIdx.x & 31, rs = threadIdx.x >> 5;
   if ((p.C & 3) == 0) {
-    const int64_t e = ((int64_t)blockIdx.x * 32 + cq) << 2;
+    const int64_t e = ((int64_t)blk * 32 + cq) << 2;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < total) {
       int r = rs;
@@ -43,11 +43,22 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) {
 #pragma unroll
       for (int q = 1; q < 8; ++q) { const float4 b = red[q][cq]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
       const int64_t row = e / p.C, c = e - row * p.C;
-      float* o = row < p.rows1 ? p.out + row * p.ld_out + c : p.tail_out + (row - p.rows1) * p.C + c;
-      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+      if (p.pair_split) {          // columns are (a, b) pairs: a_k -> out[k], b_k -> tail_out[k] (or out[ld_out + k])
+        float* const ob = p.tail_out ? p.tail_out : p.out + p.ld_out;
+        const int k = (int)(c >> 1);
+        p.out[k] = t.x; ob[k] = t.y; p.out[k + 1] = t.z; ob[k + 1] = t.w;
+      } else if (row < p.rows1) {
+        float* o = p.out + row * p.ld_out + c;
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+      } else {
+        const int64_t i = (row - p.rows1) * p.C + c;      // tail: only its first tail_n values exist at the destination
+        float* o = p.tail_out + i;
+        if (i + 3 < p.tail_n) { o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+        else { if (i < p.tail_n) o[0] = t.x; if (i + 1 < p.tail_n) o[1] = t.y; if (i + 2 < p.tail_n) o[2] = t.z; }
+      }
     }
   } else {
-    const int64_t e = (int64_t)blockIdx.x * 32 + cq;
+    const int64_t e = (int64_t)blk * 32 + cq;
     float a = 0.f;
     if (e < total)
       for (int r = rs; r < p.R; r += 8) a += p.in[(int64_t)r * total + e];
@@ -58,9 +69,38 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) t += reinterpret_cast<float*>(red)[q * 32 + cq];
       const int64_t row = e / p.C;
-      if (row < p.rows1) p.out[row * p.ld_out + (e - row * p.C)] = t;
-      else p.tail_out[(row - p.rows1) * p.C + (e - row * p.C)] = t;
+      if (p.pair_split) ((e & 1) ? (p.tail_out ? p.tail_out : p.out + p.ld_out) : p.out)[e >> 1] = t;
+      else if (row < p.rows1) p.out[row * p.ld_out + (e - row * p.C)] = t;
+      else if ((row - p.rows1) * p.C + (e - row * p.C) < p.tail_n) p.tail_out[(row - p.rows1) * p.C + (e - row * p.C)] = t;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void fold_rows_kernel(const FoldK p) { fold_rows_block(p, blockIdx.x); }
+
+// every slab fold of a backward pass in ONE launch (the expert fine-tune step issued 357 of them, 7.8 us each): items[] in
+// device memory, starts[i] = first 32-quad unit of item i.  A workgroup takes FOLD_UNITS consecutive units: one bisection of
+// the table per workgroup (nine dependent loads: per unit they cost more than the fold itself), then a walk.
+constexpr int FOLD_UNITS = 16;
+__device__ __forceinline__ FoldK fold_item(const AptpFoldRowsParams& it) {
+  return FoldK{it.partials, it.out, it.R, it.n_rows, it.C, it.ld_out, it.tail_out, it.n_rows - it.tail_rows, it.pair_split,
+               it.tail_n > 0 ? it.tail_n : it.tail_rows * it.C};
+}
+__global__ __launch_bounds__(256) void fold_rows_many_kernel(const AptpFoldRowsParams* __restrict__ items,
+                                                             const int32_t* __restrict__ starts, int n_items, int total_units) {
+  int u = blockIdx.x * FOLD_UNITS;
+  const int u_end = u + FOLD_UNITS < total_units ? u + FOLD_UNITS : total_units;
+  int lo = 0, hi = n_items;                     // invariant: starts[lo] <= u < starts[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (starts[mid] <= u) lo = mid; else hi = mid;
+  }
+  int s0 = starts[lo], s1 = starts[lo + 1];
+  FoldK k = fold_item(items[lo]);
+  for (; u < u_end; ++u) {
+    while (u >= s1) { ++lo; s0 = s1; s1 = starts[lo + 1]; k = fold_item(items[lo]); }
+    __syncthreads();                            // (the staging array of the previous unit is free)
+    fold_rows_block(k, u - s0);
   }
 }
 
@@ -122,15 +162,36 @@ __global__ __launch_bounds__(256) void pack_dgrad_many_kernel(const AptpPackDgra
 #define ALIGN16(p) (((uintptr_t)(p) % 16) == 0)
 
 extern "C" int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream) {
-  APTP_CHECK(p && p->partials && p->out && p->R >= 1 && p->n_rows >= 1 && p->C >= 1 && p->ld_out >= p->C, "fold_rows: bad arguments");
+  APTP_CHECK(p && p->partials && p->out && p->R >= 1 && p->n_rows >= 1 && p->C >= 1 && (p->ld_out >= p->C || (p->pair_split && 2 * p->ld_out >= p->C)),
+             "fold_rows: bad arguments");
   APTP_CHECK((p->C & 3) != 0 || (ALIGN16(p->partials) && (((int64_t)p->n_rows * p->C) & 3) == 0), "fold_rows: alignment");
-  APTP_CHECK(p->tail_rows >= 0 && p->tail_rows < p->n_rows && (p->tail_rows == 0 || p->tail_out), "fold_rows: tail");
-  FoldK k{p->partials, p->out, p->R, p->n_rows, p->C, p->ld_out, p->tail_out, p->n_rows - p->tail_rows};
+  APTP_CHECK(!p->pair_split || (p->n_rows == 1 && p->tail_rows == 0 && (p->C & 1) == 0), "fold_rows: pair_split folds ONE row of (a, b) pairs");
+  APTP_CHECK(p->tail_rows >= 0 && (p->pair_split || p->tail_rows < p->n_rows) && (p->tail_rows == 0 || p->tail_out), "fold_rows: tail");
+  APTP_CHECK(p->tail_n >= 0 && p->tail_n <= p->tail_rows * p->C, "fold_rows: tail_n");
+  FoldK k{p->partials, p->out, p->R, p->n_rows, p->C, p->ld_out, p->tail_out, p->n_rows - p->tail_rows, p->pair_split,
+          p->tail_n > 0 ? p->tail_n : p->tail_rows * p->C};
   const int64_t total = (int64_t)p->n_rows * p->C;
   const int64_t work = (p->C & 3) == 0 ? total / 4 : total;          // column quads (or single columns), 32 per block
   const int64_t blocks = (work + 31) / 32;
   APTP_CHECK(blocks < (1LL << 31), "fold_rows: grid too large");
   hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}
+
+extern "C" int aptp_fold_rows_blocks(const AptpFoldRowsParams* p) {
+  if (!p || p->n_rows < 1 || p->C < 1) return 0;
+  const int64_t total = (int64_t)p->n_rows * p->C;
+  const int64_t work = (p->C & 3) == 0 ? total / 4 : total;
+  const int64_t blocks = (work + 31) / 32;
+  return blocks < (1LL << 31) ? (int)blocks : 0;
+}
+
+extern "C" int aptp_fold_rows_many(const AptpFoldRowsParams* items_dev, const int32_t* starts_dev, int32_t n_items,
+                                   int32_t total_blocks, aptp_stream_t stream) {
+  APTP_CHECK(items_dev && starts_dev && n_items >= 1 && total_blocks >= 1, "fold_rows_many: bad arguments");
+  hipLaunchKernelGGL(fold_rows_many_kernel, dim3((unsigned)((total_blocks + FOLD_UNITS - 1) / FOLD_UNITS)), dim3(256), 0, (hipStream_t)stream,
+                     items_dev, starts_dev, n_items, total_blocks);
   APTP_LAUNCH_CHECK();
   return APTP_OK;
 }

@@ -952,27 +952,102 @@ def mse_bwd(a: torch.Tensor, b: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
 
 
 def fold_rows(partials: torch.Tensor, n_rows: int, C: int, out: Optional[torch.Tensor] = None,
-              tail_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              tail_out: Optional[torch.Tensor] = None, deferrable: bool = False, pair_split: bool = False,
+              tail_n: int = 0, pair_out=None) -> torch.Tensor:
     """out[row, c] = sum_r partials[r, row, c] (fp32, fixed order); partials is [R, n_rows (+ tail rows), C] contiguous; `out` may
     be a [n_rows, ld >= C] buffer whose extra columns are left alone (the padded packed layout of a weight gradient).
     tail_out (fp32, contiguous, a multiple of C elements): the rows after the first n_rows are summed into it instead -- the
     bias-gradient slabs that ride behind a weight gradient's slabs, folded by the same launch."""
     lib = _lib.load()
-    tail_rows = 0 if tail_out is None else tail_out.numel() // C
+    if pair_split and pair_out is not None:
+        # (a, b) pairs straight into two existing gradient tensors (direct-gradient mode): a -> pair_out[0], b -> pair_out[1]
+        a_t, b_t = pair_out
+        assert n_rows == 1 and C % 2 == 0 and a_t.dtype == b_t.dtype == torch.float32 and a_t.is_contiguous() and b_t.is_contiguous() \
+            and a_t.numel() >= C // 2 and b_t.numel() >= C // 2
+        assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() % C == 0
+        p = FoldRowsParams()
+        p.partials, p.out, p.R, p.n_rows, p.C, p.ld_out = partials.data_ptr(), a_t.data_ptr(), partials.numel() // C, 1, C, C
+        p.tail_out, p.tail_rows, p.pair_split = b_t.data_ptr(), 0, 1
+        if FOLD_DEFER is not None and deferrable:
+            FOLD_DEFER.append({"params": p, "keep": (partials, a_t, b_t)})
+        else:
+            _lib.check(lib.aptp_fold_rows(ctypes.byref(p), _stream()), "aptp_fold_rows")
+        return None
+    if tail_n:
+        # the tail destination holds tail_n values (a bias gradient written in place); the slabs carry whole rows of C
+        tail_rows = (tail_n + C - 1) // C
+        assert tail_out is not None and tail_out.dtype == torch.float32 and tail_out.is_contiguous() and tail_out.numel() >= tail_n
+    else:
+        tail_rows = 0 if tail_out is None else tail_out.numel() // C
     total_rows = n_rows + tail_rows
     assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() % (total_rows * C) == 0
     R = partials.numel() // (total_rows * C)
-    if out is None:
-        out = torch.empty(n_rows, C, dtype=torch.float32, device=partials.device)
-    o2 = out.reshape(n_rows, -1)
-    assert o2.dtype == torch.float32 and o2.stride(1) == 1 and o2.shape[1] >= C and (n_rows == 1 or o2.stride(0) == o2.shape[1])
+    if pair_split:
+        # one row of (a, b) pairs -> out [2, half]: a in row 0, b in row 1 (half = C/2 rounded up to 4: both rows 16-byte aligned)
+        assert n_rows == 1 and tail_out is None and out is None and C % 2 == 0
+        half = round_up(C // 2, 4)
+        out = torch.empty(2, half, dtype=torch.float32, device=partials.device)
+        o2 = out
+    else:
+        if out is None:
+            out = torch.empty(n_rows, C, dtype=torch.float32, device=partials.device)
+        o2 = out.reshape(n_rows, -1)
+        assert o2.dtype == torch.float32 and o2.stride(1) == 1 and o2.shape[1] >= C and (n_rows == 1 or o2.stride(0) == o2.shape[1])
     p = FoldRowsParams()
     p.partials, p.out, p.R, p.n_rows, p.C, p.ld_out = partials.data_ptr(), o2.data_ptr(), R, total_rows, C, o2.shape[1]
     if tail_out is not None:
-        assert tail_out.dtype == torch.float32 and tail_out.is_contiguous() and tail_out.numel() == tail_rows * C
-        p.tail_out, p.tail_rows = tail_out.data_ptr(), tail_rows
+        assert tail_out.dtype == torch.float32 and tail_out.is_contiguous() and (tail_n or tail_out.numel() == tail_rows * C)
+        p.tail_out, p.tail_rows, p.tail_n = tail_out.data_ptr(), tail_rows, int(tail_n)
+    p.pair_split = int(pair_split)          # (n_rows == 1: out = [C/2 first-of-pair sums | C/2 second-of-pair sums])
+    if FOLD_DEFER is not None and deferrable:
+        # deferred: the caller of the backward folds everything at once (FoldBatch); `out` is returned UNWRITTEN and must not be
+        # read before that (weight / bias gradients: nothing reads them before the optimizer)
+        FOLD_DEFER.append({"params": p, "keep": (partials, out, tail_out)})
+        return out
     _lib.check(lib.aptp_fold_rows(ctypes.byref(p), _stream()), "aptp_fold_rows")
     return out
+
+
+# Deferred slab folds.  The weight-gradient kernel splits the pixel range over workgroups and leaves fp32 slabs; summing them is
+# one fold launch per weight -- 357 launches of 7.8 us in the expert fine-tune step, 2.8 ms of 39.  Nothing reads a weight (or
+# bias) gradient before the optimizer, so with FOLD_DEFER set to a list the folds of a backward pass are only RECORDED (slabs and
+# destinations stay referenced, so a capturing allocator cannot hand their memory to a later kernel), and FoldBatch runs them as
+# ONE launch over a descriptor table in device memory -- after the replayed graph, next to the one-launch AdamW
+# (train_step.GraphedFineTunerStep).  Bitwise the same sums as the single folds (same kernel body, same order).
+FOLD_DEFER = None
+
+# Direct parameter gradients (train_step.GraphedFineTunerStep sets it around its warm-up and capture).  The packed trainable
+# tensors own PERSISTENT, zero-initialised .grad buffers, and the weight-gradient kernel, the slab folds and the norm-affine
+# folds write their results straight into them; the autograd Functions return None for those inputs.  Autograd's
+# AccumulateGrad is out of the loop: it clones any incoming gradient another object still references (a recorded, not yet
+# executed fold) -- i.e. it would read the buffer BEFORE the fold wrote it -- and each fresh gradient tensor with pad
+# columns cost a zero fill per step (80 launches).  Every parameter is used once per step, so "write" equals "accumulate".
+GRAD_DIRECT = False
+
+
+class FoldBatch:
+    def __init__(self, records):
+        lib = _lib.load()
+        records = list(records)
+        assert records
+        dev = records[0]["keep"][0].device
+        items = (FoldRowsParams * len(records))()
+        starts = [0]
+        for i, rec in enumerate(records):
+            ctypes.memmove(ctypes.byref(items[i]), ctypes.byref(rec["params"]), ctypes.sizeof(FoldRowsParams))
+            nb = lib.aptp_fold_rows_blocks(ctypes.byref(items[i]))
+            assert nb > 0
+            starts.append(starts[-1] + nb)
+        assert starts[-1] < 2 ** 31
+        self.items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(dev)
+        self.n, self.total = len(records), starts[-1]
+        self.keep = [r["keep"] for r in records]
+
+    def run(self):
+        lib = _lib.load()
+        _lib.check(lib.aptp_fold_rows_many(self.items.data_ptr(), self.starts.data_ptr(), self.n, self.total, _stream()),
+                   "aptp_fold_rows_many")
 
 
 def pack_dgrad_from_packed(pw: PackedWeight, pwb: PackedWeight) -> PackedWeight:
@@ -1120,7 +1195,7 @@ def depth_lerp_bwd(dy: torch.Tensor, x_in: torch.Tensor, x_out: torch.Tensor, d:
 
 
 def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
-                  silu: bool, stats: torch.Tensor, C: Optional[int] = None, want_pgrad: bool = False):
+                  silu: bool, stats: torch.Tensor, C: Optional[int] = None, want_pgrad: bool = False, pgrad_out=None):
     """dx (and, with want_pgrad, (dgamma, dbeta) fp32 [C]) of GroupNorm(+SiLU); C = real channel count when the
     tensor is padded to a multiple of 8."""
     lib = _lib.load()
@@ -1142,12 +1217,16 @@ def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: 
         p.pgrad_partial = part.data_ptr()
     _lib.check(lib.aptp_groupnorm_bwd(ctypes.byref(p), _stream()), "aptp_groupnorm_bwd")
     if want_pgrad:
-        pg = fold_rows(part.view(-1, 1, C * 2), 1, C * 2).view(C, 2)
-        return dx, pg[:, 1].contiguous(), pg[:, 0].contiguous()
+        # (dbeta, dgamma) pairs -> two contiguous [C] gradients straight from the fold (was: one [C, 2] tensor + two strided copies)
+        if pgrad_out is not None:          # (dgamma, dbeta) destinations: the parameters' own gradient buffers
+            fold_rows(part.view(-1, 1, C * 2), 1, C * 2, deferrable=True, pair_split=True, pair_out=(pgrad_out[1], pgrad_out[0]))
+            return dx, None, None
+        pg = fold_rows(part.view(-1, 1, C * 2), 1, C * 2, deferrable=True, pair_split=True)
+        return dx, pg[1, :C], pg[0, :C]
     return dx
 
 
-def layernorm_pgrad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5):
+def layernorm_pgrad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5, pgrad_out=None):
     """(dgamma, dbeta) fp32 [C] of LayerNorm over the last dim."""
     lib = _lib.load()
     B, L, C, ldx = _rows(x)
@@ -1157,8 +1236,11 @@ def layernorm_pgrad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5):
     p = LayerNormPgradParams()
     p.x, p.ldx, p.dy, p.lddy, p.rows, p.C, p.eps, p.partial = x.data_ptr(), ldx, dy.data_ptr(), lddy, B * L, C, eps, part.data_ptr()
     _lib.check(lib.aptp_layernorm_pgrad(ctypes.byref(p), _stream()), "aptp_layernorm_pgrad")
-    pg = fold_rows(part.view(-1, 1, C * 2), 1, C * 2).view(C, 2)
-    return pg[:, 1].contiguous(), pg[:, 0].contiguous()
+    if pgrad_out is not None:
+        fold_rows(part.view(-1, 1, C * 2), 1, C * 2, deferrable=True, pair_split=True, pair_out=(pgrad_out[1], pgrad_out[0]))
+        return None, None
+    pg = fold_rows(part.view(-1, 1, C * 2), 1, C * 2, deferrable=True, pair_split=True)
+    return pg[1, :C], pg[0, :C]
 
 
 def colsum(x: torch.Tensor, per_sample: bool = False) -> torch.Tensor:
@@ -1233,7 +1315,8 @@ WGRAD_RESAMPLE = os.environ.get("APTP_WGRAD_RESAMPLE", "1") != "0"    # stride-2
 
 
 def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: Optional[int] = None,
-                  out: Optional[torch.Tensor] = None, want_db: bool = False, stride: int = 1, ups: int = 0):
+                  out: Optional[torch.Tensor] = None, want_db: bool = False, stride: int = 1, ups: int = 0,
+                  db_out: Optional[torch.Tensor] = None):
     """x [B,H,W,C], dy [B,H,W,N] (bf16, channels contiguous, uniform pixel stride) -> fp32 [N, KH*KW, C] or None when
     the geometry is not handled by aptp_conv_wgrad.  out: an fp32 [N, KH*KW, ld >= C] buffer (a packed-layout gradient) that
     receives the result in its first C columns (the rest is left alone); returned instead of a fresh tensor."""
@@ -1256,8 +1339,10 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
         p.split_m = max(1, min(-(-WGRAD_SPLIT_TARGET // tiles), max(1, nsteps // 4), 64))
     if out is not None:
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[:2]) == (N, KH * KW) and out.shape[2] >= C
+    if db_out is not None:
+        assert want_db and db_out.dtype == torch.float32 and db_out.is_contiguous() and db_out.numel() >= N
     if p.split_m == 1:
-        db = torch.empty(N, dtype=torch.float32, device=x.device) if want_db else None
+        db = (db_out if db_out is not None else torch.empty(N, dtype=torch.float32, device=x.device)) if want_db else None
         if want_db:
             p.db = db.data_ptr()
         res = out if out is not None else torch.empty(N, KH * KW, C, dtype=torch.float32, device=x.device)
@@ -1272,9 +1357,10 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
     if want_db:
         p.slab_stride = (rows + dbrows) * C
         p.db, p.db_stride = slabs.data_ptr() + rows * C * 4, (rows + dbrows) * C
-        tail = torch.empty(dbrows * C, dtype=torch.float32, device=x.device)    # (entries past N: sums of unwritten slab floats, unused)
+        tail = torch.empty(dbrows * C, dtype=torch.float32, device=x.device) if db_out is None else db_out
     _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
-    res = fold_rows(slabs, rows, C, out=out, tail_out=tail)
+    # (tail entries past N are sums of unwritten slab floats: unused, and never written when the destination is db_out)
+    res = fold_rows(slabs, rows, C, out=out, tail_out=tail, deferrable=True, tail_n=(N if db_out is not None else 0))
     res = res if out is not None else res.view(N, KH * KW, C)
     return (res, tail[:N]) if want_db else res
 
@@ -1365,7 +1451,7 @@ def _wgrad_parity(x: torch.Tensor, dy: torch.Tensor, stride: int, ups: int, out:
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int = 1, pad: int = 0, ups: int = 0,
-               out: Optional[torch.Tensor] = None, want_db: bool = False):
+               out: Optional[torch.Tensor] = None, want_db: bool = False, db_out: Optional[torch.Tensor] = None):
     """Weight gradient of y = conv(x, w): returns fp32 [N, KH*KW, C] (the packed-weight order, unpadded), or `out` (fp32
     [N, KH*KW, ld >= C], e.g. a zero-initialised packed-layout gradient) with the result in its first C columns.
     x [B,H,W,C] (or tokens [B,L,C] with KH=KW=1), dy [B,Ho,Wo,N] (or [B,L,N]); both bf16.
@@ -1376,7 +1462,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
         x, dy = x.reshape(1, -1, 1, x.shape[-1]), dy.reshape(1, -1, 1, dy.shape[-1])
     C, N = x.shape[-1], dy.shape[-1]
     if WGRAD_KERNEL and stride == 1 and ups == 0 and KH == KW and pad == KH // 2 and x.shape[:3] == dy.shape[:3]:
-        g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db)
+        g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db, db_out=db_out)
         if g is not None:
             return g
     # the six resampling convolutions of the U-Net (3x3: stride-2 down-samplers, nearest-x2 up-samplers): the same kernel with
@@ -1384,7 +1470,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     if (WGRAD_KERNEL and WGRAD_RESAMPLE and KH == 3 and KW == 3 and pad == 1 and x.dim() == 4 and x.shape[0] == dy.shape[0]
             and ((stride == 2 and ups == 0 and x.shape[1] == 2 * dy.shape[1] and x.shape[2] == 2 * dy.shape[2])
                  or (stride == 1 and ups == 1 and dy.shape[1] == 2 * x.shape[1] and dy.shape[2] == 2 * x.shape[2]))):
-        g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db, stride=stride, ups=ups)
+        g = _wgrad_direct(x, dy, KH, KW, out=out, want_db=want_db, stride=stride, ups=ups, db_out=db_out)
         if g is not None:
             return g
     # resampling convolutions: the parity split only pays where the fine grid is large and the weight small -- it runs the
@@ -1392,7 +1478,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     # upsample to 64x64 at 640 / 352 channels 449 vs 810 / 259 vs 396; every other resampling layer of SD-2.1 is 1.2-3.5x
     # SLOWER that way, e.g. 704 vs 199 at 8x8 / 1280 channels), so the rule is narrow
     if (WGRAD_KERNEL and WGRAD_PARITY and KH == 3 and KW == 3 and pad == 1 and x.dim() == 4 and stride == 1 and ups == 1
-            and dy.shape[0] * dy.shape[1] * dy.shape[2] >= 16384 and x.shape[-1] * dy.shape[-1] <= 640 * 640):
+            and dy.shape[0] * dy.shape[1] * dy.shape[2] >= 16384 and x.shape[-1] * dy.shape[-1] <= 640 * 640 and db_out is None):
         g = _wgrad_parity(x, dy, stride, ups, out, want_db)
         if g is not None:
             return g
@@ -1415,4 +1501,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, stride: int 
     if out is not None:
         out[:, :, :C] = res
         res = out
+    if want_db and db_out is not None:
+        db_out[:N].copy_(colsum(dy))
+        return res, db_out[:N]
     return (res, colsum(dy)) if want_db else res

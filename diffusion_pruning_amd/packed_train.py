@@ -176,6 +176,15 @@ class PackedTrainer:
             ps += [a.Pg, a.Pb]
         return ps
 
+    @torch.no_grad()
+    def ensure_grad_buffers(self):
+        """persistent, zero-initialised .grad for every packed tensor (direct-gradient mode, ops.GRAD_DIRECT): the kernels write
+        the live region of each buffer every step and never touch the pad columns"""
+        for p in self.parameters():
+            if p.grad is None or p.grad.shape != p.shape:
+                p.grad = torch.zeros_like(p)
+        return self
+
     def named_parameters(self):
         """(stable name, packed tensor) pairs: the diffusers name of the parameter an entry was packed from + the kind of the
         packed tensor, so optimizer state can be matched by NAME on resume (the registry's own order is the first-run order

@@ -703,6 +703,7 @@ class GraphedFineTunerStep(FineTunerStep):
         # packed tensors' .grad; they are averaged over the ranks in buckets (no hooks: nothing of a replay runs on the
         # host) between the replay and the one-launch AdamW
         self._dp_graphed, self._bucket_bytes, self._reduce_mode = data_parallel, bucket_bytes, reduce_mode
+        self.defer_folds, self.direct_grads, self._folds = True, True, None
         from .packed_train import PackedTrainer
         self.trainer = PackedTrainer(student).attach()
         self.opt_kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
@@ -754,10 +755,16 @@ class GraphedFineTunerStep(FineTunerStep):
             torch.cuda.empty_cache()
         params = self.trainer.parameters()
         out = {}
+        # direct-gradient mode (ops.GRAD_DIRECT): persistent gradient buffers written by the kernels / the deferred folds; nothing
+        # to reset between steps -- every parameter's live region is overwritten by each backward
+        direct = self.direct_grads
+        if direct:
+            self.trainer.ensure_grad_buffers()
 
         def fwd_bwd():
-            for p in params:
-                p.grad = None
+            if not direct:
+                for p in params:
+                    p.grad = None
             with torch.no_grad():
                 full_pred = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
             pred = self.student(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
@@ -768,15 +775,30 @@ class GraphedFineTunerStep(FineTunerStep):
         # warm-up (allocator, plan caches, autograd's stream anchors) runs forward + backward only: nothing to undo afterwards
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for i in range(warmup_iters):
-                fwd_bwd()
+        ops.GRAD_DIRECT = direct
+        try:
+            with torch.cuda.stream(side):
+                for i in range(warmup_iters):
+                    fwd_bwd()
+        finally:
+            ops.GRAD_DIRECT = False
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         log0 = None if ops.LAUNCH_LOG is None else len(ops.LAUNCH_LOG)     # (bench.py: the contractions of ONE captured step)
         graph = new_graph()
-        with torch.cuda.graph(graph):
-            fwd_bwd()
+        # The slab folds of the split weight gradients (and the chunk folds of the norm-affine gradients) are only RECORDED while
+        # the backward is captured and run as ONE launch behind every replay (ops.FoldBatch: 357 launches of ~8 us otherwise):
+        # nothing reads a parameter gradient before the optimizer.
+        ops.FOLD_DEFER = [] if (self.defer_folds and direct) else None
+        ops.GRAD_DIRECT = direct
+        try:
+            with torch.cuda.graph(graph):
+                fwd_bwd()
+            folds = ops.FOLD_DEFER
+        finally:
+            ops.FOLD_DEFER = None
+            ops.GRAD_DIRECT = False
+        self._folds = ops.FoldBatch(folds) if folds else None
         launch_log = None if log0 is None else ops.LAUNCH_LOG[log0:]
         # The optimizer is ONE launch over every trainable tensor and writes the bf16 operands in the same pass
         # (packed_train.PackedAdamW, csrc/optim.hip); its table holds the addresses of the gradients the captured backward
@@ -792,7 +814,12 @@ class GraphedFineTunerStep(FineTunerStep):
 
     def graph_nodes(self):
         """nodes of the captured teacher + student forward / backward graph, when it was kept (graph_utils.KEEP_GRAPHS)"""
-        return None if self._cap is None else {"fwd_bwd": node_count(self._cap["graph"])}
+        if self._cap is None:
+            return None
+        n = {"fwd_bwd": node_count(self._cap["graph"])}
+        if self._folds is not None:
+            n["deferred_folds_launch"] = 1
+        return n
 
     def train_step(self, optimizer=None, batch: Optional[dict] = None):
         """one replayed step on `batch` (same shapes as the captured one); `optimizer` is ignored: the fused AdamW built at
@@ -804,6 +831,8 @@ class GraphedFineTunerStep(FineTunerStep):
                 cap["st"][k].copy_(batch[k])
             cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
         cap["graph"].replay()
+        if self._folds is not None:
+            self._folds.run()                    # every deferred slab / chunk fold of the backward: one launch
         if self._dp_graphed and self.reducer is not None:
             self.reducer.exchange_all()          # mean over the ranks, written in place (the optimizer's table holds these addresses)
         self.optimizer.step()

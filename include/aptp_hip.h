@@ -433,8 +433,20 @@ typedef struct {
   const float* partials; float* out; int32_t R, n_rows, C, ld_out;
   float* tail_out; int32_t tail_rows;   /* optional: the LAST tail_rows of the n_rows go to tail_out (fp32 [tail_rows][C], contiguous)
                                            instead of out -- a weight gradient's slabs and its bias gradient's slabs in one fold */
+  int32_t pair_split;                   /* 1 (n_rows == 1, C even): the columns are (a, b) pairs -- the (dbeta, dgamma) partials of the norm
+                                           backward kernels -- and out receives a_k at [k], b_k at [ld_out + k]: two contiguous
+                                           parameter gradients without a strided copy each; b goes to tail_out when that is set (two separate gradient
+                                           tensors), else to out + ld_out (>= C/2) */
+  int32_t tail_n;                       /* 0 = every tail value; otherwise only the first tail_n of the tail_rows * C tail values are written
+                                           (a bias gradient of N values whose slabs were padded to whole rows of C) */
 } AptpFoldRowsParams;
 int aptp_fold_rows(const AptpFoldRowsParams* p, aptp_stream_t stream);
+/* many folds as ONE launch: items_dev = n_items parameter blocks in DEVICE memory (each valid for aptp_fold_rows), starts_dev =
+ * n_items + 1 int32 prefix sums of aptp_fold_rows_blocks() (starts[n_items] = total_blocks).  The expert fine-tune step folds the
+ * slabs of every split weight gradient this way after its backward (FineTuner.step, trainer.py:1616). */
+int aptp_fold_rows_blocks(const AptpFoldRowsParams* p);
+int aptp_fold_rows_many(const AptpFoldRowsParams* items_dev, const int32_t* starts_dev, int32_t n_items, int32_t total_blocks,
+                        aptp_stream_t stream);
 
 /* AdamW (torch.optim.AdamW arithmetic: decoupled weight decay, bias correction, fp32) over many tensors in ONE launch, writing
  * the bf16 operand the GEMM kernels read in the same pass (the optimizer step of FineTuner.step, pdm/training/trainer.py:1529-1540,

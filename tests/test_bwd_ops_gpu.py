@@ -407,6 +407,43 @@ def test_fold_rows_and_pack_dgrad_from_packed(ops, cuda):
         assert torch.equal(dst.w, want.w)
 
 
+def test_deferred_folds_in_one_launch_equal_the_single_folds(ops, cuda):
+    """ops.FOLD_DEFER / ops.FoldBatch: the slab folds of a backward pass recorded and run as ONE launch over a device table are
+    bitwise the single folds (padded destination, bias tail rows, scalar path); pair_split writes the (dbeta, dgamma) pairs of
+    the norm backward kernels as two contiguous, 16-byte aligned gradients (C = 170: the halves are padded apart)"""
+    g = torch.Generator().manual_seed(2)
+    specs = [(5, 7, 24, 40, 0), (3, 1, 10, 10, 0), (12, 136 * 9, 72, 128, 2), (64, 33, 8, 8, 0), (2, 640, 320, 320, 0)]
+    parts = [torch.randn(R, rows + tail, C, generator=g).to(cuda) for (R, rows, C, ld, tail) in specs]
+    outs_a = [torch.full((rows, ld), -1.0, device=cuda) for (R, rows, C, ld, tail) in specs]
+    outs_b = [o.clone() for o in outs_a]
+    tails_a = [torch.zeros(tail * C, device=cuda) if tail else None for (R, rows, C, ld, tail) in specs]
+    tails_b = [None if t is None else t.clone() for t in tails_a]
+    for pt, o, t, (R, rows, C, ld, tail) in zip(parts, outs_a, tails_a, specs):
+        ops.fold_rows(pt, rows, C, out=o, tail_out=t)
+    pair = torch.randn(9, 1, 340, generator=g).to(cuda)
+    want_pair = ops.fold_rows(pair, 1, 340).view(170, 2)
+    ops.FOLD_DEFER = []
+    try:
+        for pt, o, t, (R, rows, C, ld, tail) in zip(parts, outs_b, tails_b, specs):
+            r = ops.fold_rows(pt, rows, C, out=o, tail_out=t, deferrable=True)
+            assert r is o
+        pg = ops.fold_rows(pair, 1, 340, deferrable=True, pair_split=True)
+        not_deferred = ops.fold_rows(parts[0], 7, 24)                   # call sites that read their result at once stay immediate
+        recs = ops.FOLD_DEFER
+    finally:
+        ops.FOLD_DEFER = None
+    assert len(recs) == len(specs) + 1 and torch.allclose(not_deferred, parts[0].sum(0), atol=1e-5)
+    assert bool((outs_b[0] == -1).all())                               # nothing ran yet
+    ops.FoldBatch(recs).run()
+    torch.cuda.synchronize()
+    for a, b, ta, tb in zip(outs_a, outs_b, tails_a, tails_b):
+        assert torch.equal(a, b) and (ta is None or torch.equal(ta, tb))
+    assert pg.shape == (2, 172) and pg[1].data_ptr() % 16 == 0
+    assert torch.equal(pg[0, :170], want_pair[:, 0]) and torch.equal(pg[1, :170], want_pair[:, 1])
+    now = ops.fold_rows(pair, 1, 340, pair_split=True)                  # the immediate form of pair_split
+    assert torch.equal(now[:, :170], pg[:, :170])
+
+
 @pytest.mark.parametrize("case", ["bf16_nhwc", "bf16_slice", "f32_nchw", "bf16_big", "odd_rows", "nchw_face"])
 def test_mse_matches_torch_fp64(cuda, case):
     """ops.mse / autograd.MseFn (csrc/loss_ops.hip) vs F.mse_loss in fp64: value to fp32 summation accuracy, gradient to the

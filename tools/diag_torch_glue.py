@@ -19,6 +19,9 @@ THRESH = (1 << 18) if FT else (1 << 20)
 COPIES = "--copies" in sys.argv  # only copy-like ops, from 16 K elements up
 if COPIES:
     THRESH = 1 << 14
+ALL = "--all" in sys.argv        # every torch op that launches something, ranked by COUNT (the launch diet's view)
+if ALL:
+    THRESH = 1
 dev = torch.device("cuda:0")
 unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
 unet.freeze()
@@ -86,7 +89,7 @@ with Big() as big:
     run()
 torch.cuda.synchronize()
 tot = 0
-for k, n in sorted(big.c.items(), key=lambda kv: -big.bytes[kv[0]])[:40]:
+for k, n in sorted(big.c.items(), key=lambda kv: (-kv[1] if ALL else -big.bytes[kv[0]]))[:(70 if ALL else 40)]:
     print(f"{n:4d} x {big.bytes[k] / n / 1e6:7.1f} MB  {k[0]:36s} {k[1]}")
     tot += big.bytes[k]
-print("total output bytes of big torch ops per step: %.1f MB" % (tot / 1e6))
+print("total output bytes of big torch ops per step: %.1f MB; %d torch ops counted" % (tot / 1e6, sum(big.c.values())))

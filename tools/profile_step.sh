@@ -16,6 +16,12 @@ cd "$R"
 f=$(find "/tmp/prof_$tag" -name '*kernel_trace.csv' | head -1)
 s=$(find "/tmp/prof_$tag" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && [ -n "$s" ] || { echo "profile_step: rocprofv3 wrote no trace (see gpurun_out/${tag}_prof.log)"; exit 1; }
-python tools/trace_breakdown.py "$f" > "gpurun_out/${tag}_breakdown.txt" || echo "(no periodic tail found: see the stats csv)" > "gpurun_out/${tag}_breakdown.txt"
+# PROFILE_MARKER=<kernel that runs once per step>: per-step averages between its occurrences (training steps: several graphs on
+# two streams + eager launches have no single periodic sequence); default: one period of the replayed forward graph
+if [ -n "${PROFILE_MARKER:-}" ]; then
+  python tools/trace_breakdown.py "$f" "$PROFILE_MARKER" 8 > "gpurun_out/${tag}_breakdown.txt"
+else
+  python tools/trace_breakdown.py "$f" > "gpurun_out/${tag}_breakdown.txt" || echo "(no periodic tail found: see the stats csv)" > "gpurun_out/${tag}_breakdown.txt"
+fi
 cp "$s" "gpurun_out/${tag}_kernel_stats.csv"
 head -"$lines" "gpurun_out/${tag}_breakdown.txt"

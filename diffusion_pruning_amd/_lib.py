@@ -267,6 +267,10 @@ EXPORTS = [
     ("aptp_conv_wgrad_supported", c_int, [POINTER(WgradParams)]),
     ("aptp_conv_wgrad_suggest_split", c_int, [POINTER(WgradParams)]),
     ("aptp_conv_wgrad", c_int, [POINTER(WgradParams), c_void_p]),
+    ("aptp_conv_wgrad_many_item_bytes", ctypes.c_int64, []),
+    ("aptp_conv_wgrad_many_blocks", c_int, [POINTER(WgradParams)]),
+    ("aptp_conv_wgrad_many_fill", c_int, [POINTER(WgradParams), c_void_p, ctypes.c_int32]),
+    ("aptp_conv_wgrad_many", c_int, [c_void_p, c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void_p]),
     ("aptp_fold_rows", c_int, [POINTER(FoldRowsParams), c_void_p]),
     ("aptp_pack_dgrad", c_int, [POINTER(PackDgradParams), c_void_p]),
     ("aptp_fold_rows_blocks", c_int, [POINTER(FoldRowsParams)]),

@@ -26,6 +26,7 @@
 // GEMMs on transposed torch copies, or as four stride-1 calls on parity planes that compute 36 tap results to use 9.)
 #include "aptp_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -42,6 +43,8 @@ struct WgK {
   int ldw;             // row length of dw's c dimension
   float* db;           // optional [split][N]: column sums of dy over the slice (written by the workgroups of c-block 0)
   int64_t slab_stride, db_stride;
+  int first_block;     // conv_wgrad_many_kernel: the item's first workgroup in the batch's grid
+  int pad_;
 };
 
 #define APTP_WGRAD_SUB_DEFAULT 2      // measured on the fine-tune step: 38.3 / 37.7 / 38.0 ms with 1 / 2 / 4
@@ -61,8 +64,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* lds_row_q_col_4p, int pl
 
 // SUB: 32-pixel sub-steps per barrier.  The 3x3 form stages one halo per 32 pixels (SUB = 1); a 1x1 / linear layer has no halo
 // and only 4 MFMAs per wave and sub-step, so it takes 64 pixels per barrier (SUB = 2; 4 fits too -- 74 KB of LDS -- and measures the same).
-template <int TAPS, int SUB, int STRIDE = 1>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
+template <int TAPS, int SUB, int STRIDE>
+__device__ __forceinline__ void wgrad_body(const WgK& p, int bid) {
   static_assert(TAPS == 1 || SUB == 1, "sub-steps only without a halo");
   static_assert(STRIDE == 1 || TAPS == 9, "stride 2: the 3x3 down-samplers");
   constexpr int XR = STRIDE == 2 ? XROWS_S2 : XROWS;
@@ -72,7 +75,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wc = wave & 1;
-  int bid = blockIdx.x;
   const int slice = bid % p.split; bid /= p.split;
   const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
   const int n0 = tn * 64, c0 = tc * 64;
@@ -222,6 +224,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
   }
 }
 
+template <int TAPS, int SUB, int STRIDE = 1>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p) {
+  wgrad_body<TAPS, SUB, STRIDE>(p, (int)blockIdx.x);
+}
+
+// Every stride-1 weight gradient of a backward pass as ONE launch (per filter size).  Issued layer by layer, each launch has to
+// fill the chip on its own, so a 176 x 176 projection at 16,384 pixels was cut into 57 pixel slices (9 dW tiles x 57 = 513
+// workgroups of 9 steps, 57 fp32 slabs to fold afterwards); batched, the grid is every layer's tiles and a slice is as long
+// as a workgroup is worth starting for (~2,048 pixels): 8 slices there, none for the large weights, whose gradients are
+// then written straight into the optimizer's buffer.  Descriptors (WgK, filled by aptp_conv_wgrad_many_fill) and the
+// workgroup -> item map live in device memory; both loads are wave-uniform.
+template <int TAPS, int SUB>
+__global__ __launch_bounds__(256) void conv_wgrad_many_kernel(const WgK* __restrict__ items, const int* __restrict__ block_item) {
+  const int it = block_item[blockIdx.x];
+  const WgK p = items[it];
+  wgrad_body<TAPS, SUB, 1>(p, (int)blockIdx.x - p.first_block);
+}
+
 }  // namespace
 
 #define ALIGN16(p) (((uintptr_t)(p) % 16) == 0)
@@ -249,20 +269,22 @@ extern "C" int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p) {
   return split > 64 ? 64 : split;
 }
 
-extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
+static int sub_1x1() {
+  // sub-steps per barrier of the 1x1 form (APTP_WGRAD_SUB = 1 / 2 / 4 for A/B timing)
+  static const int sub_env = [] { const char* e = getenv("APTP_WGRAD_SUB"); return e ? atoi(e) : 0; }();
+  return (sub_env == 1 || sub_env == 2 || sub_env == 4) ? sub_env : APTP_WGRAD_SUB_DEFAULT;
+}
+
+static int fill_wgk(const AptpWgradParams* p, WgK& k, int SUB1, int& stride_out) {
   APTP_CHECK(p && p->x && p->dy && p->dw, "conv_wgrad: null pointer");
   APTP_CHECK(aptp_conv_wgrad_supported(p), "conv_wgrad: unsupported geometry (KH=%d KW=%d H=%d W=%d C=%d N=%d)", p->KH, p->KW, p->H, p->W, p->C, p->N);
   APTP_CHECK(ALIGN16(p->x) && ALIGN16(p->dy) && ALIGN16(p->dw) && p->split_m >= 1, "conv_wgrad: alignment / split");
-  WgK k;
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dw = p->dw;
   k.B = p->B; k.H = p->H; k.W = p->W; k.C = p->C; k.N = p->N; k.HW = p->H * p->W; k.M = p->B * k.HW;
   const int stride = p->stride == 2 ? 2 : 1;
   k.ups = p->ups ? 1 : 0;
   k.Hin = stride == 2 ? 2 * p->H : (k.ups ? p->H / 2 : p->H);
   k.Win = stride == 2 ? 2 * p->W : (k.ups ? p->W / 2 : p->W);
-  // sub-steps per barrier of the 1x1 form (APTP_WGRAD_SUB = 1 / 2 / 4 for A/B timing)
-  static const int sub_env = [] { const char* e = getenv("APTP_WGRAD_SUB"); return e ? atoi(e) : 0; }();
-  const int SUB1 = (sub_env == 1 || sub_env == 2 || sub_env == 4) ? sub_env : APTP_WGRAD_SUB_DEFAULT;
   k.nsteps = p->KH == 3 ? (k.M + 31) / 32 : (k.M + 32 * SUB1 - 1) / (32 * SUB1);
   k.ldw = p->ld_dw ? p->ld_dw : p->C;
   k.db = p->db;
@@ -275,6 +297,17 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   k.tiles_n = (p->N + 63) / 64; k.tiles_c = (p->C + 63) / 64;
   k.Wt = p->W < 32 ? p->W : 32; k.R = p->W < 32 ? 32 / p->W : 1; k.hw2 = stride * (k.Wt - 1) + 3;
   APTP_CHECK(p->KH == 1 || (stride * (k.R - 1) + 3) * k.hw2 <= (stride == 2 ? XROWS_S2 : XROWS), "conv_wgrad: halo does not fit");
+  k.first_block = 0; k.pad_ = 0;
+  stride_out = stride;
+  return APTP_OK;
+}
+
+extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
+  WgK k;
+  int stride = 1;
+  const int SUB1 = sub_1x1();
+  const int rc = fill_wgk(p, k, SUB1, stride);
+  if (rc != APTP_OK) return rc;
   const int64_t nblk = (int64_t)k.tiles_n * k.tiles_c * k.split;
   APTP_CHECK(nblk < (1LL << 31), "conv_wgrad: grid too large");
   if (p->KH == 3 && stride == 2) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1, 2>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
@@ -282,6 +315,39 @@ extern "C" int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream) {
   else if (SUB1 == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
   else if (SUB1 == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
   else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+  APTP_LAUNCH_CHECK();
+  return APTP_OK;
+}
+
+// ---- batched form ----------------------------------------------------------------------------------------------------------
+extern "C" int64_t aptp_conv_wgrad_many_item_bytes() { return (int64_t)sizeof(WgK); }
+
+extern "C" int aptp_conv_wgrad_many_blocks(const AptpWgradParams* p) {
+  if (!p || p->split_m < 1) return -1;
+  const int64_t n = (int64_t)((p->N + 63) / 64) * ((p->C + 63) / 64) * p->split_m;
+  return n < (1LL << 30) ? (int)n : -1;
+}
+
+extern "C" int aptp_conv_wgrad_many_fill(const AptpWgradParams* p, void* item_out, int32_t first_block) {
+  APTP_CHECK(item_out, "conv_wgrad_many_fill: null item");
+  APTP_CHECK(p && (p->stride == 0 || p->stride == 1) && !p->ups, "conv_wgrad_many: stride-1 layers only (the resampling layers take aptp_conv_wgrad)");
+  WgK k;
+  int stride = 1;
+  const int rc = fill_wgk(p, k, APTP_WGRAD_SUB_DEFAULT, stride);
+  if (rc != APTP_OK) return rc;
+  k.first_block = first_block;
+  memcpy(item_out, &k, sizeof(WgK));
+  return APTP_OK;
+}
+
+extern "C" int aptp_conv_wgrad_many(const void* items_dev, const int32_t* block_item_dev, int32_t n_items, int32_t total_blocks,
+                                    int32_t taps, aptp_stream_t stream) {
+  APTP_CHECK(items_dev && block_item_dev && n_items > 0 && total_blocks > 0, "conv_wgrad_many: empty batch");
+  APTP_CHECK(taps == 1 || taps == 9, "conv_wgrad_many: taps %d", taps);
+  APTP_CHECK(ALIGN16(items_dev), "conv_wgrad_many: descriptor table alignment");
+  const WgK* items = (const WgK*)items_dev;
+  if (taps == 9) hipLaunchKernelGGL((conv_wgrad_many_kernel<9, 1>), dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items, block_item_dev);
+  else hipLaunchKernelGGL((conv_wgrad_many_kernel<1, APTP_WGRAD_SUB_DEFAULT>), dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items, block_item_dev);
   APTP_LAUNCH_CHECK();
   return APTP_OK;
 }

@@ -1050,6 +1050,56 @@ class FoldBatch:
                    "aptp_fold_rows_many")
 
 
+# Batched weight gradients (round 3).  Issued layer by layer, each aptp_conv_wgrad launch has to fill the chip on its own: a
+# 176 x 176 projection at 16,384 pixels becomes 9 tiles x 57 pixel slices and 57 fp32 slabs to fold.  With WGRAD_DEFER set to a list
+# (the graphed fine-tune step, direct-gradient mode) the stride-1 launches of a backward are only recorded -- operands are kept
+# alive by the record -- and WgradBatch runs them as one launch per filter size afterwards, slices of ~WGRAD_BATCH_SLICE pixels:
+# most weights need no slabs at all and their gradients go straight into the optimizer's buffer.  Run it BEFORE the FoldBatch of
+# the same backward (the remaining slabs are folded there).
+WGRAD_DEFER = None
+WGRAD_SPLIT_RULE = "launch"        # "batch": per-layer launches use the batch's pixel split too (bitwise comparisons with a batched step)
+WGRAD_BATCH_SLICE = int(os.environ.get("APTP_WGRAD_BATCH_SLICE", "2048"))
+
+
+class WgradBatch:
+    def __init__(self, records):
+        lib = _lib.load()
+        records = list(records)
+        assert records
+        dev = records[0]["keep"][0].device
+        nbytes = int(lib.aptp_conv_wgrad_many_item_bytes())
+        self.groups = []
+        self.keep = [r["keep"] for r in records]
+        for taps in (1, 9):
+            recs = [r for r in records if r["taps"] == taps]
+            if not recs:
+                continue
+            # long slices first: the short ones (small maps) fill the tail of the grid
+            recs.sort(key=lambda r: -((r["params"].B * r["params"].H * r["params"].W) // r["params"].split_m))
+            table = (ctypes.c_uint8 * (nbytes * len(recs)))()
+            block_item, first = [], 0
+            for i, r in enumerate(recs):
+                nb = lib.aptp_conv_wgrad_many_blocks(ctypes.byref(r["params"]))
+                assert nb > 0
+                _lib.check(lib.aptp_conv_wgrad_many_fill(ctypes.byref(r["params"]), ctypes.addressof(table) + i * nbytes, first),
+                           "aptp_conv_wgrad_many_fill")
+                block_item.append(torch.full((nb,), i, dtype=torch.int32))
+                first += nb
+            assert first < 2 ** 31
+            items = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+            assert items.data_ptr() % 16 == 0
+            self.groups.append((taps, items, torch.cat(block_item).to(dev), len(recs), first))
+
+    def run(self):
+        lib = _lib.load()
+        for taps, items, block_item, n, total in self.groups:
+            _lib.check(lib.aptp_conv_wgrad_many(items.data_ptr(), block_item.data_ptr(), n, total, taps, _stream()),
+                       "aptp_conv_wgrad_many")
+
+    def launches(self):
+        return len(self.groups)
+
+
 def pack_dgrad_from_packed(pw: PackedWeight, pwb: PackedWeight) -> PackedWeight:
     """refresh the data-gradient operand `pwb` (ops.pack_weight_dgrad layout) from the forward operand `pw` of the same
     weights, bf16 -> bf16, one launch"""
@@ -1331,8 +1381,19 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
         return None
     _check_act(x, "conv_wgrad x")
     _check_act(dy, "conv_wgrad dy")
+    # batched mode (WGRAD_DEFER): the launch is only RECORDED -- every stride-1 weight gradient of the backward runs as one launch
+    # per filter size when the backward is complete (WgradBatch), so a pixel slice only has to be worth a workgroup
+    defer = WGRAD_DEFER is not None and out is not None and stride == 1 and ups == 0 and (not want_db or db_out is not None)
     p.split_m = int(split_m) if split_m else lib.aptp_conv_wgrad_suggest_split(ctypes.byref(p))
-    if not split_m and WGRAD_SPLIT_TARGET:
+    if not split_m and stride == 1 and ups == 0 and (defer or WGRAD_SPLIT_RULE == "batch"):
+        p.split_m = max(1, min(64, (B * H * W + WGRAD_BATCH_SLICE // 2) // WGRAD_BATCH_SLICE))
+
+    def launch():
+        if defer:
+            WGRAD_DEFER.append({"params": p, "taps": KH * KW, "keep": (x, dy, out, db_out)})
+        else:
+            _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
+    if not split_m and WGRAD_SPLIT_TARGET and not defer and WGRAD_SPLIT_RULE != "batch":
         # (A/B of the pixel-range split: workgroups wanted per launch; the library's own rule is 512)
         tiles = ((N + 63) // 64) * ((C + 63) // 64)
         nsteps = (B * H * W + 31) // 32
@@ -1347,7 +1408,7 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
             p.db = db.data_ptr()
         res = out if out is not None else torch.empty(N, KH * KW, C, dtype=torch.float32, device=x.device)
         p.dw, p.ld_dw = res.data_ptr(), res.shape[2]
-        _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
+        launch()
         return (res, db) if want_db else res
     # slabs: [split][N*taps rows of C | ceil(N / C) more rows holding the slice's N bias-gradient sums]; ONE fold for both
     rows, dbrows = N * KH * KW, ((N + C - 1) // C if want_db else 0)
@@ -1358,7 +1419,9 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
         p.slab_stride = (rows + dbrows) * C
         p.db, p.db_stride = slabs.data_ptr() + rows * C * 4, (rows + dbrows) * C
         tail = torch.empty(dbrows * C, dtype=torch.float32, device=x.device) if db_out is None else db_out
-    _lib.check(lib.aptp_conv_wgrad(ctypes.byref(p), _stream()), "aptp_conv_wgrad")
+    launch()
+    if defer:
+        WGRAD_DEFER[-1]["keep"] += (slabs,)
     # (tail entries past N are sums of unwritten slab floats: unused, and never written when the destination is db_out)
     res = fold_rows(slabs, rows, C, out=out, tail_out=tail, deferrable=True, tail_n=(N if db_out is not None else 0))
     res = res if out is not None else res.view(N, KH * KW, C)

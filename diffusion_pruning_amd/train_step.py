@@ -704,6 +704,7 @@ class GraphedFineTunerStep(FineTunerStep):
         # host) between the replay and the one-launch AdamW
         self._dp_graphed, self._bucket_bytes, self._reduce_mode = data_parallel, bucket_bytes, reduce_mode
         self.defer_folds, self.direct_grads, self._folds = True, True, None
+        self.defer_wgrads, self._wgrads = True, None
         from .packed_train import PackedTrainer
         self.trainer = PackedTrainer(student).attach()
         self.opt_kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
@@ -789,15 +790,20 @@ class GraphedFineTunerStep(FineTunerStep):
         # The slab folds of the split weight gradients (and the chunk folds of the norm-affine gradients) are only RECORDED while
         # the backward is captured and run as ONE launch behind every replay (ops.FoldBatch: 357 launches of ~8 us otherwise):
         # nothing reads a parameter gradient before the optimizer.
+        # Likewise the stride-1 weight gradients: recorded, then ONE launch per filter size behind the replay (ops.WgradBatch),
+        # with pixel slices sized for the batch instead of for a chip-filling launch each (most weights: no slabs, no fold).
         ops.FOLD_DEFER = [] if (self.defer_folds and direct) else None
+        ops.WGRAD_DEFER = [] if (self.defer_wgrads and self.defer_folds and direct) else None
         ops.GRAD_DIRECT = direct
         try:
             with torch.cuda.graph(graph):
                 fwd_bwd()
-            folds = ops.FOLD_DEFER
+            folds, wgrads = ops.FOLD_DEFER, ops.WGRAD_DEFER
         finally:
             ops.FOLD_DEFER = None
+            ops.WGRAD_DEFER = None
             ops.GRAD_DIRECT = False
+        self._wgrads = ops.WgradBatch(wgrads) if wgrads else None
         self._folds = ops.FoldBatch(folds) if folds else None
         launch_log = None if log0 is None else ops.LAUNCH_LOG[log0:]
         # The optimizer is ONE launch over every trainable tensor and writes the bf16 operands in the same pass
@@ -817,6 +823,8 @@ class GraphedFineTunerStep(FineTunerStep):
         if self._cap is None:
             return None
         n = {"fwd_bwd": node_count(self._cap["graph"])}
+        if self._wgrads is not None:
+            n["batched_wgrad_launches"] = self._wgrads.launches()
         if self._folds is not None:
             n["deferred_folds_launch"] = 1
         return n
@@ -831,6 +839,8 @@ class GraphedFineTunerStep(FineTunerStep):
                 cap["st"][k].copy_(batch[k])
             cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
         cap["graph"].replay()
+        if self._wgrads is not None:
+            self._wgrads.run()                   # every stride-1 weight gradient of the backward: one launch per filter size
         if self._folds is not None:
             self._folds.run()                    # every deferred slab / chunk fold of the backward: one launch
         if self._dp_graphed and self.reducer is not None:

@@ -427,6 +427,19 @@ int aptp_conv_wgrad_supported(const AptpWgradParams* p);
 int aptp_conv_wgrad_suggest_split(const AptpWgradParams* p);
 int aptp_conv_wgrad(const AptpWgradParams* p, aptp_stream_t stream);
 
+/* Every stride-1 weight gradient of a backward pass as ONE launch per filter size (round 3; replaces 225 + 43 per-layer launches
+ * of the expert fine-tune step, i.e. F.conv2d / F.linear weight gradients of trainer.py:1616 issued when the backward is
+ * complete).  Per item the caller chooses split_m for the BATCH (a pixel slice only has to be worth a workgroup, not to fill the
+ * chip: ~2,048 pixels), fills one descriptor of aptp_conv_wgrad_many_item_bytes() bytes with aptp_conv_wgrad_many_fill (host
+ * memory; first_block = sum of aptp_conv_wgrad_many_blocks() of the items before it), uploads the descriptor table (16-byte
+ * aligned) and an int32 map block -> item of total_blocks entries, and launches.  All items of one call share `taps` (1 or 9);
+ * results, slabs and bias-gradient slabs exactly as aptp_conv_wgrad with the same split_m (bit-identical). */
+int64_t aptp_conv_wgrad_many_item_bytes(void);
+int aptp_conv_wgrad_many_blocks(const AptpWgradParams* p);
+int aptp_conv_wgrad_many_fill(const AptpWgradParams* p, void* item_out, int32_t first_block);
+int aptp_conv_wgrad_many(const void* items_dev, const int32_t* block_item_dev, int32_t n_items, int32_t total_blocks,
+                         int32_t taps, aptp_stream_t stream);
+
 /* out[row][c] = sum over r < R of partials[r][row][c] (partials: fp32 [R][n_rows][C] contiguous; out: fp32 [n_rows][ld_out]); fixed order.
  * The slab sum of a split weight gradient (written into the padded packed layout) and the chunk sums of bias / affine gradients. */
 typedef struct {

@@ -444,6 +444,66 @@ def test_deferred_folds_in_one_launch_equal_the_single_folds(ops, cuda):
     assert torch.equal(now[:, :170], pg[:, :170])
 
 
+def test_batched_weight_gradients_equal_the_single_launches(ops, cuda):
+    """ops.WGRAD_DEFER / ops.WgradBatch (aptp_conv_wgrad_many): the stride-1 weight gradients of a backward recorded and run as one
+    launch per filter size are bitwise the per-layer launches with the same pixel split -- direct destinations with a padded
+    leading dimension, slabs + bias-gradient tail folded afterwards, ragged N / C, strided dy (a slice of a fused buffer) -- and
+    with the batch's own split rule they equal an fp32 reference to summation accuracy"""
+    g = torch.Generator().manual_seed(11)
+    # (B, H, W, C, N, K, split_m, want_db)
+    specs = [(2, 32, 32, 176, 176, 1, 4, True), (2, 16, 16, 352, 704, 1, 1, True), (1, 8, 8, 72, 40, 1, 2, False),
+             (2, 32, 32, 176, 96, 3, 3, True), (2, 16, 16, 136, 352, 3, 1, True), (4, 8, 8, 64, 64, 3, 1, False),
+             (2, 64, 64, 24, 8, 1, 8, True)]
+
+    def operands():
+        out = []
+        for (B, H, W, C, N, K, sm, wdb) in specs:
+            x = torch.randn(B, H, W, C, generator=g).to(cuda, torch.bfloat16)
+            buf = torch.randn(B, H, W, N + 16, generator=g).to(cuda, torch.bfloat16)
+            out.append((x, buf[..., 8:8 + N] if N % 16 == 0 else buf[..., :N].contiguous()))
+        return out
+    opnds = operands()
+
+    def run(split_rule):
+        res = []
+        for (x, dy), (B, H, W, C, N, K, sm, wdb) in zip(opnds, specs):
+            ld = ops.round_up(C, 64)
+            out = torch.full((N, K * K, ld), -3.0, device=cuda)
+            db = torch.full((N,), -3.0, device=cuda) if wdb else None
+            r = ops._wgrad_direct(x, dy, K, K, split_m=(sm if split_rule == "given" else None), out=out, want_db=wdb, db_out=db)
+            assert r is not None
+            res.append((out, db))
+        return res
+    want = run("given")
+    torch.cuda.synchronize()
+    for rule in ("given", "batch"):
+        ops.WGRAD_DEFER, ops.FOLD_DEFER = [], []
+        try:
+            got = run(rule)
+            wrec, frec = ops.WGRAD_DEFER, ops.FOLD_DEFER
+        finally:
+            ops.WGRAD_DEFER, ops.FOLD_DEFER = None, None
+        assert len(wrec) == len(specs) and bool((got[1][0][:, :, :352] == -3).all())          # nothing ran yet
+        batch = ops.WgradBatch(wrec)
+        assert batch.launches() == 2
+        batch.run()
+        if frec:
+            ops.FoldBatch(frec).run()
+        torch.cuda.synchronize()
+        for (a, da), (b, db_), (x, dy), (B, H, W, C, N, K, sm, wdb) in zip(want, got, opnds, specs):
+            if rule == "given":
+                assert torch.equal(a, b) and (da is None or torch.equal(da, db_))
+            else:
+                xf = x.float().permute(0, 3, 1, 2)
+                cols = torch.nn.functional.unfold(xf, K, padding=K // 2).view(B, C, K * K, H * W)
+                ref = torch.einsum("bctm,bmn->ntc", cols, dy.float().reshape(B, H * W, N))
+                tol = 2e-5 * float(ref.abs().max()) + 1e-4
+                assert float((b[:, :, :C] - ref).abs().max()) <= tol
+                assert bool((b[:, :, C:] == -3).all())                                         # the padding columns are left alone
+                if wdb:
+                    assert torch.allclose(db_, dy.float().sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("case", ["bf16_nhwc", "bf16_slice", "f32_nchw", "bf16_big", "odd_rows", "nchw_face"])
 def test_mse_matches_torch_fp64(cuda, case):
     """ops.mse / autograd.MseFn (csrc/loss_ops.hip) vs F.mse_loss in fp64: value to fp32 summation accuracy, gradient to the

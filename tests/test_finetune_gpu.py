@@ -171,7 +171,7 @@ def test_no_grad_forward_and_state_dict_follow_the_packed_state(cuda):
     check(rel_l2(y_inf, y_eval), 2e-2, "inference forward on exported masters vs no-grad forward on the packed state")
 
 
-def test_graphed_finetune_step_equals_the_eager_packed_step(cuda):
+def test_graphed_finetune_step_equals_the_eager_packed_step(cuda, monkeypatch):
     """GraphedFineTunerStep (teacher forward; student forward + losses + backward + fused AdamW + operand refresh as HIP
     graphs) reproduces the eager packed step: losses of three consecutive steps and the parameters after them"""
     from diffusion_pruning_amd.packed_train import PackedTrainer
@@ -189,6 +189,10 @@ def test_graphed_finetune_step_equals_the_eager_packed_step(cuda):
     # test_one_launch_adamw_matches_torch_adamw
     ref, opt = [], None
     p0 = [p.detach().clone() for p in pk.parameters()]
+    # (the graphed step runs its weight gradients as one batched launch with the batch's pixel split: the eager step takes the
+    #  same split here, so the two stay bitwise comparable)
+    from diffusion_pruning_amd import ops as _ops
+    monkeypatch.setattr(_ops, "WGRAD_SPLIT_RULE", "batch")
     for i, b in enumerate(batches):
         for p in pk.parameters():
             p.grad = None

@@ -191,6 +191,7 @@ class GroupNormBwdParams(Structure):
         ("fwd_stats", c_void_p),
         ("workspace", c_void_p),
         ("pgrad_partial", c_void_p),
+        ("add", c_void_p), ("ldadd", c_int64),
     ]
 
 
@@ -226,6 +227,7 @@ class LayerNormBwdParams(Structure):
         ("rows", c_int32), ("C", c_int32),
         ("gamma", c_void_p),
         ("eps", c_float),
+        ("add", c_void_p), ("ldadd", c_int64),
     ]
 
 

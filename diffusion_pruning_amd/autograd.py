@@ -102,34 +102,55 @@ class GateFn(Function):
         return dx, dgate.to(gate.dtype) if ctx.needs_input_grad[1] else None
 
 
+# Residual forks.  Every sub-block of the U-Net is `x + f(norm(x))`: x feeds the norm AND the `+ x` at the end, so autograd sums
+# two gradients for it with an elementwise launch (~160 per training step).  With fork=True the norm Functions return
+# (y, x_res): x_res aliases x and is what the caller hands to the `+ x` epilogue; the Function then receives BOTH gradients and
+# the norm's backward kernel adds the residual one while it writes dx (fp32 sum, rounded once) -- no separate add.
+def _fork_add(dres, like):
+    if dres is None:
+        return None
+    assert dres.shape == like.shape
+    return _c(dres)
+
+
 class GroupNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups: int, eps: float, silu: bool):
+    def forward(ctx, x, gamma, beta, groups: int, eps: float, silu: bool, fork: bool = False):
         y, stats = ops.groupnorm(x, gamma, beta, groups, eps, silu, keep_stats=True)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.meta = (groups, eps, silu)
+        if fork:
+            ctx.set_materialize_grads(False)
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, stats = ctx.saved_tensors
         groups, eps, silu = ctx.meta
-        return ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats), None, None, None, None, None
+        if dy is None:                                 # (only the residual path carries gradient)
+            return dres, None, None, None, None, None, None
+        return ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, add=_fork_add(dres, x)), None, None, None, None, None, None
 
 
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float):
+    def forward(ctx, x, gamma, beta, eps: float, fork: bool = False):
         x = _c(x)
         y = ops.layernorm(x, gamma, beta, eps)
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
+        if fork:
+            ctx.set_materialize_grads(False)
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma = ctx.saved_tensors
-        return ops.layernorm_bwd(x, _c(dy), gamma, ctx.eps), None, None, None
+        if dy is None:
+            return dres, None, None, None, None
+        return ops.layernorm_bwd(x, _c(dy), gamma, ctx.eps, add=_fork_add(dres, x)), None, None, None, None
 
 
 class SelfAttnFn(Function):
@@ -403,45 +424,59 @@ class GroupNormWFn(Function):
     """GroupNorm(+SiLU) with trainable affine; `live` = channel indices of a compacted tensor (norm2 of a pruned resnet)."""
 
     @staticmethod
-    def forward(ctx, x, gamma_p, beta_p, gamma, beta, groups: int, eps: float, silu: bool, C: int, live: Optional[torch.Tensor]):
+    def forward(ctx, x, gamma_p, beta_p, gamma, beta, groups: int, eps: float, silu: bool, C: int, live: Optional[torch.Tensor],
+                fork: bool = False):
         y, stats = ops.groupnorm(x, gamma, beta, groups, eps, silu, C=C, keep_stats=True)
         ctx.save_for_backward(x, gamma, beta, stats, gamma_p, live if live is not None else torch.zeros(0, dtype=torch.long, device=x.device))
         ctx.meta = (groups, eps, silu, C, live is not None)
         ctx.params = (gamma_p, beta_p)
+        if fork:                                       # (residual fork: see GroupNormFn)
+            ctx.set_materialize_grads(False)
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, stats, gamma_p, live = ctx.saved_tensors
         groups, eps, silu, C, has_live = ctx.meta
         want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         gp, bp = ctx.params
+        nones = (None,) * 10
+        if dy is None:
+            return (dres,) + nones
+        add = _fork_add(dres, x)
         if ops.GRAD_DIRECT and want and not has_live and gp.grad is not None and bp.grad is not None and gp.grad.numel() == C:
-            dx, _, _ = ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, C=C, want_pgrad=True, pgrad_out=(gp.grad, bp.grad))
-            return dx, None, None, None, None, None, None, None, None, None
-        res = ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, C=C, want_pgrad=want)
+            dx, _, _ = ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, C=C, want_pgrad=True, pgrad_out=(gp.grad, bp.grad),
+                                         add=add)
+            return (dx,) + nones
+        res = ops.groupnorm_bwd(x, _c(dy), gamma, beta, groups, eps, silu, stats, C=C, want_pgrad=want, add=add)
         if not want:
-            return res, None, None, None, None, None, None, None, None, None
+            return (res,) + nones
         dx, dgamma, dbeta = res
         idx = live if has_live else None
-        return dx, _scatter_rows(gamma_p, dgamma, idx), _scatter_rows(gamma_p, dbeta, idx), None, None, None, None, None, None, None
+        return (dx, _scatter_rows(gamma_p, dgamma, idx), _scatter_rows(gamma_p, dbeta, idx)) + nones[:8]
 
 
 class LayerNormWFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma_p, beta_p, gamma, beta, eps: float):
+    def forward(ctx, x, gamma_p, beta_p, gamma, beta, eps: float, fork: bool = False):
         x = _c(x)
         y = ops.layernorm(x, gamma, beta, eps)
         ctx.save_for_backward(x, gamma, gamma_p)
         ctx.eps = eps
         ctx.params = (gamma_p, beta_p)
+        if fork:                                       # (residual fork: see GroupNormFn)
+            ctx.set_materialize_grads(False)
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, gamma_p = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None, None, None
         dy = _c(dy)
-        dx = ops.layernorm_bwd(x, dy, gamma, ctx.eps)
+        dx = ops.layernorm_bwd(x, dy, gamma, ctx.eps, add=_fork_add(dres, x))
         dg = db = None
         gp, bp = ctx.params
         if ops.GRAD_DIRECT and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and gp.grad is not None and bp.grad is not None \
@@ -450,4 +485,4 @@ class LayerNormWFn(Function):
         elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dgamma, dbeta = ops.layernorm_pgrad(x, dy, ctx.eps)
             dg, db = dgamma.to(gamma_p.dtype), dbeta.to(gamma_p.dtype)
-        return dx, dg, db, None, None, None
+        return dx, dg, db, None, None, None, None

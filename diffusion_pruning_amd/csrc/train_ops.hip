@@ -332,6 +332,7 @@ struct GnBwdK {
   const float* fstats;   // forward partials [B, nchunk, G, 2] (sum, sumsq)
   float* bpart;          // backward partials [B, nchunk, G, 2] (S1, S2)
   float* pgrad;          // optional per-channel partials [B, nchunk, C, 2] (sum dz, sum dz*xh) -> dbeta, dgamma
+  const __bf16* add; int64_t ldadd;   // optional: dx += add (the gradient arriving over the residual path that forked at x)
 };
 
 __device__ __forceinline__ void fold_forward_stats(const GnBwdK& p, int b, int tid, float* mean_s, float* rstd_s) {
@@ -432,7 +433,15 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdK p) {
               if (APPLY) dxv[e] = rs[pg][e] * (dz * ga[pg][e] - m1[pg][e] - xh * m2[pg][e]);
               else { a1[pg][e] += dz; a2v[pg][e] += dz * xh; }
             }
-            if (APPLY) *reinterpret_cast<u32x4*>(p.dx + (row0 + (h ? rb : r)) * p.lddx + o * 8) = pack8(dxv);
+            if (APPLY) {
+              if (p.add) {
+                float ad[8];
+                unpack8(*reinterpret_cast<const u32x4*>(p.add + (row0 + (h ? rb : r)) * p.ldadd + o * 8), ad);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dxv[e] += ad[e];
+              }
+              *reinterpret_cast<u32x4*>(p.dx + (row0 + (h ? rb : r)) * p.lddx + o * 8) = pack8(dxv);
+            }
           }
         }
       }
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const GnBwdK p) {
 struct LnBwdK {
   const __bf16* x; int64_t ldx; const __bf16* dy; int64_t lddy; __bf16* dx; int64_t lddx;
   int rows, C, CO; const float* gamma; float eps;
+  const __bf16* add; int64_t ldadd;   // optional: dx += add (residual-path gradient of the fork at x)
 };
 
 template <int NO>
@@ -545,6 +555,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdK p) {
       float o8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o8[e] = rstd * (d[i][e] - s1 - x[i][e] * s2);
+      if (p.add) {
+        float ad[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p.add + (int64_t)row * p.ldadd + o * 8), ad);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] += ad[e];
+      }
       *reinterpret_cast<u32x4*>(p.dx + (int64_t)row * p.lddx + o * 8) = pack8(o8);
     }
   }
@@ -783,6 +799,8 @@ extern "C" int aptp_groupnorm_bwd(const AptpGroupNormBwdParams* p, aptp_stream_t
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dx = (__bf16*)p->dx; k.lddx = p->lddx;
   k.gamma = p->gamma; k.beta = p->beta; k.eps = p->eps; k.silu = p->silu;
   k.fstats = p->fwd_stats; k.bpart = (float*)p->workspace; k.pgrad = p->pgrad_partial;
+  k.add = (const __bf16*)p->add; k.ldadd = p->ldadd;
+  APTP_CHECK(!p->add || (p->ldadd % 8 == 0 && ALIGN16(p->add)), "groupnorm_bwd: add alignment");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(k.r.nchunk, p->B);
   if (k.r.CO <= 256) {
@@ -803,6 +821,8 @@ extern "C" int aptp_layernorm_bwd(const AptpLayerNormBwdParams* p, aptp_stream_t
   LnBwdK k;
   k.x = (const __bf16*)p->x; k.ldx = p->ldx; k.dy = (const __bf16*)p->dy; k.lddy = p->lddy; k.dx = (__bf16*)p->dx; k.lddx = p->lddx;
   k.rows = p->rows; k.C = p->C; k.CO = p->C / 8; k.gamma = p->gamma; k.eps = p->eps;
+  k.add = (const __bf16*)p->add; k.ldadd = p->ldadd;
+  APTP_CHECK(!p->add || (p->ldadd % 8 == 0 && ALIGN16(p->add)), "layernorm_bwd: add alignment");
   dim3 grid((p->rows + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   switch ((k.CO + 63) / 64) {

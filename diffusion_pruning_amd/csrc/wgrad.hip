@@ -330,7 +330,7 @@ extern "C" int aptp_conv_wgrad_many_blocks(const AptpWgradParams* p) {
 
 extern "C" int aptp_conv_wgrad_many_fill(const AptpWgradParams* p, void* item_out, int32_t first_block) {
   APTP_CHECK(item_out, "conv_wgrad_many_fill: null item");
-  APTP_CHECK(p && (p->stride == 0 || p->stride == 1) && !p->ups, "conv_wgrad_many: stride-1 layers only (the resampling layers take aptp_conv_wgrad)");
+  APTP_CHECK(p && (p->stride == 0 || p->stride == 1), "conv_wgrad_many: stride-1 layers only (incl. the folded nearest-x2 up-sample; the stride-2 layers take aptp_conv_wgrad)");
   WgK k;
   int stride = 1;
   const int rc = fill_wgk(p, k, APTP_WGRAD_SUB_DEFAULT, stride);

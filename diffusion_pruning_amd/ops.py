@@ -189,6 +189,7 @@ def pack_weight_cat(pw: PackedWeight, w2: torch.Tensor, bias2: Optional[torch.Te
 
 
 _ws_cache = {}
+_ws_capture_keep = []      # see _workspace
 
 def tuning_key(M, N, Cin, taps, stride, ups, geglu, Cin2: int = 0) -> str:
     return f"M{M}_N{N}_C{Cin}_T{taps}_s{stride}u{ups}g{int(bool(geglu))}" + (f"x{Cin2}" if Cin2 else "")
@@ -272,11 +273,12 @@ GN_LAUNCH_LOG = None
 # Split-K launches combine their K-slices inside the kernel (AptpConvGemmParams.tile_counters) instead of launching
 # splitk_reduce_kernel; False restores the two-launch form (A/B timing, tests of both forms)
 SPLITK_IN_KERNEL = True
+SPLITK_FORCE_IN_KERNEL = os.environ.get("APTP_SPLITK_FORCE_INKERNEL", "0") == "1"
 _counters = {}
 _N_COUNTERS = 1 << 16
 
 
-_N_SLABS = 16
+_N_SLABS = int(os.environ.get("APTP_N_SLABS", "16"))
 _counters_lock = threading.Lock()
 
 
@@ -359,6 +361,15 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if key[1]:
+            # Allocated while a stream is capturing: the block comes from that graph's private pool and its address is baked into
+            # every launch captured with it -- possibly into graphs captured LATER on the same stream, which may outlive the graph
+            # that owns the pool.  torch.cuda.graph.__enter__ empties the cache, so once the owning graph is gone and a larger
+            # request has replaced the buffer here, the block would be returned to the device while a younger graph still
+            # writes to it (seen as "Memory access fault ... write access to a read-only page" when a code object was mapped
+            # there, and only for some test orders).  A capture-time scratch buffer is therefore never released: a few grow
+            # steps per (stream, domain), bounded by the largest request.
+            _ws_capture_keep.append(buf)
         _ws_cache[key] = buf
     return buf
 
@@ -598,6 +609,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         colstats = False
         p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_C, p.gn_silu, p.gn_eps = gamma.data_ptr(), beta.data_ptr(), groups, Cn, int(silu_), eps_
     if p.split_k > 1:
+        if SPLITK_FORCE_IN_KERNEL and not gn_fused:
+            in_kernel = True               # (A/B switch: every split launch combines its slices itself, no reduce launches)
         if in_kernel is None:
             in_kernel = p.split_k <= 4 or explicit_split
         # only the workgroup that combines the slices can emit row / column statistics.  Column statistics are worth the
@@ -1245,9 +1258,11 @@ def depth_lerp_bwd(dy: torch.Tensor, x_in: torch.Tensor, x_out: torch.Tensor, d:
 
 
 def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
-                  silu: bool, stats: torch.Tensor, C: Optional[int] = None, want_pgrad: bool = False, pgrad_out=None):
+                  silu: bool, stats: torch.Tensor, C: Optional[int] = None, want_pgrad: bool = False, pgrad_out=None,
+                  add: Optional[torch.Tensor] = None):
     """dx (and, with want_pgrad, (dgamma, dbeta) fp32 [C]) of GroupNorm(+SiLU); C = real channel count when the
-    tensor is padded to a multiple of 8."""
+    tensor is padded to a multiple of 8.  add (bf16, x's shape): the gradient arriving over the residual path that forked
+    at x -- summed into dx in fp32 inside the kernel instead of by a separate elementwise launch."""
     lib = _lib.load()
     B, HW, Cp, ldx = _rows(x)
     C = Cp if C is None else C
@@ -1261,6 +1276,9 @@ def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: 
     p.fwd_stats = stats.data_ptr()
     ws = torch.empty_like(stats)
     p.workspace = ws.data_ptr()
+    if add is not None:
+        assert add.dtype == torch.bfloat16 and add.shape == x.shape
+        p.add, p.ldadd = add.data_ptr(), _rows(add)[3]
     part = None
     if want_pgrad:
         part = torch.empty(B, stats.shape[1], C, 2, dtype=torch.float32, device=x.device)
@@ -1310,7 +1328,9 @@ def colsum(x: torch.Tensor, per_sample: bool = False) -> torch.Tensor:
     return out if per_sample else out.view(C)
 
 
-def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5,
+                  add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """add: as in groupnorm_bwd (the residual-path gradient of the fork at x, summed inside the kernel)"""
     lib = _lib.load()
     B, L, C, ldx = _rows(x)
     _, _, _, lddy = _rows(dy)
@@ -1318,6 +1338,9 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     p = LayerNormBwdParams()
     p.x, p.ldx, p.dy, p.lddy, p.dx, p.lddx = x.data_ptr(), ldx, dy.data_ptr(), lddy, dx.data_ptr(), C
     p.rows, p.C, p.gamma, p.eps = B * L, C, gamma.data_ptr(), eps
+    if add is not None:
+        assert add.dtype == torch.bfloat16 and add.shape == x.shape
+        p.add, p.ldadd = add.data_ptr(), _rows(add)[3]
     _lib.check(lib.aptp_layernorm_bwd(ctypes.byref(p), _stream()), "aptp_layernorm_bwd")
     return dx
 
@@ -1383,9 +1406,9 @@ def _wgrad_direct(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, split_m: 
     _check_act(dy, "conv_wgrad dy")
     # batched mode (WGRAD_DEFER): the launch is only RECORDED -- every stride-1 weight gradient of the backward runs as one launch
     # per filter size when the backward is complete (WgradBatch), so a pixel slice only has to be worth a workgroup
-    defer = WGRAD_DEFER is not None and out is not None and stride == 1 and ups == 0 and (not want_db or db_out is not None)
+    defer = WGRAD_DEFER is not None and out is not None and stride == 1 and (not want_db or db_out is not None)
     p.split_m = int(split_m) if split_m else lib.aptp_conv_wgrad_suggest_split(ctypes.byref(p))
-    if not split_m and stride == 1 and ups == 0 and (defer or WGRAD_SPLIT_RULE == "batch"):
+    if not split_m and stride == 1 and (defer or WGRAD_SPLIT_RULE == "batch"):
         p.split_m = max(1, min(64, (B * H * W + WGRAD_BATCH_SLICE // 2) // WGRAD_BATCH_SLICE))
 
     def launch():

@@ -132,17 +132,17 @@ class PackedTrainer:
         return AG.conv_p(x, e.P, e.Pb, e.pw, e.get_bwd, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=residual,
                          rowbias=rowbias)
 
-    def groupnorm(self, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live):
+    def groupnorm(self, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live, fork=False):
         a = self.affines.get(id(gamma_p))
         if a is None:
             a = self.affines[id(gamma_p)] = _Affine(gamma_p, beta_p, gamma, beta, live)
-        return AG.GroupNormWFn.apply(x, a.Pg, a.Pb, a.Pg, a.Pb, groups, eps, silu, C, None)
+        return AG.GroupNormWFn.apply(x, a.Pg, a.Pb, a.Pg, a.Pb, groups, eps, silu, C, None, fork)
 
-    def layernorm(self, x, gamma_p, beta_p, gamma, beta, eps):
+    def layernorm(self, x, gamma_p, beta_p, gamma, beta, eps, fork=False):
         a = self.affines.get(id(gamma_p))
         if a is None:
             a = self.affines[id(gamma_p)] = _Affine(gamma_p, beta_p, gamma, beta, None)
-        return AG.LayerNormWFn.apply(x, a.Pg, a.Pb, a.Pg, a.Pb, eps)
+        return AG.LayerNormWFn.apply(x, a.Pg, a.Pb, a.Pg, a.Pb, eps, fork)
 
     # ---- optimizer-facing API ---------------------------------------------------------------------------------------------------
     def materialize(self, *forward_args, **forward_kwargs):

@@ -157,20 +157,22 @@ def _cw(mod, x, weight, bias, pw, get_bwd, residual=None, **kw):
     return AG.conv_w(x, weight, bias, pw, get_bwd, residual=residual, **kw)
 
 
-def _gnw(mod, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live):
+def _gnw(mod, x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live, fork=False):
+    """fork=True: returns (y, x_res) -- x_res aliases x for the sub-block's `+ x`, and the norm's backward kernel adds the
+    gradient that comes back over it (autograd.py, "Residual forks")"""
     from . import autograd as AG
     pk = mod.__dict__.get("_pk")
     if pk is not None:
-        return pk.groupnorm(x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live)
-    return AG.GroupNormWFn.apply(x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live)
+        return pk.groupnorm(x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live, fork)
+    return AG.GroupNormWFn.apply(x, gamma_p, beta_p, gamma, beta, groups, eps, silu, C, live, fork)
 
 
-def _lnw(mod, x, gamma_p, beta_p, gamma, beta, eps):
+def _lnw(mod, x, gamma_p, beta_p, gamma, beta, eps, fork=False):
     from . import autograd as AG
     pk = mod.__dict__.get("_pk")
     if pk is not None:
-        return pk.layernorm(x, gamma_p, beta_p, gamma, beta, eps)
-    return AG.LayerNormWFn.apply(x, gamma_p, beta_p, gamma, beta, eps)
+        return pk.layernorm(x, gamma_p, beta_p, gamma, beta, eps, fork)
+    return AG.LayerNormWFn.apply(x, gamma_p, beta_p, gamma, beta, eps, fork)
 
 
 def _capturing() -> bool:
@@ -362,7 +364,11 @@ class ResnetBlock2DWidthGated(nn.Module):
         x_in = x[..., :Cin - self.skip_connection_dim] if (self.depth_gated and self.is_input_concatenated) else x
         if self.depth_gated and self.dropped:
             return _nchw(x_in)
-        a1 = AG.GroupNormFn.apply(x, pl["g1"], pl["b1"], self.groups, self.eps, True)
+        x_res = None
+        if pl["wsc"] is None:                         # identity shortcut: the `+ x` of conv2 reads the norm's alias of x
+            a1, x_res = AG.GroupNormFn.apply(x, pl["g1"], pl["b1"], self.groups, self.eps, True, True)
+        else:
+            a1 = AG.GroupNormFn.apply(x, pl["g1"], pl["b1"], self.groups, self.eps, True)
         rowbias = self._temb_rowbias(temb, pl, B)
         if rowbias.shape[1] != pl["w1"].N:            # bundle was built for a compacted plan: project locally
             rowbias = self._temb_rowbias(TembBundle(emb_silu=temb.emb_silu), pl, B)
@@ -371,7 +377,7 @@ class ResnetBlock2DWidthGated(nn.Module):
         if gate.requires_grad or self.gate.hard_uniform() is None or not bool((self.gate.hard_uniform() == 1).all()):
             h = AG.GateFn.apply(h, gate.to(device=dev, dtype=torch.float32))
         a2 = AG.GroupNormFn.apply(h, pl["g2"], pl["b2"], self.groups, self.eps, True)
-        sc = x if pl["wsc"] is None else AG.conv(x, pl["wsc"], self._bwd_pack(pl, "wsc", self.conv_shortcut.weight if self.conv_shortcut is not None else None, dev), pad=0)
+        sc = x_res if pl["wsc"] is None else AG.conv(x, pl["wsc"], self._bwd_pack(pl, "wsc", self.conv_shortcut.weight if self.conv_shortcut is not None else None, dev), pad=0)
         out = AG.conv(a2, pl["w2"], self._bwd_pack(pl, "w2", self.conv2.weight, dev), residual=sc)
         if self.depth_gated:
             d = self.depth_gate.gate_f
@@ -404,7 +410,10 @@ class ResnetBlock2DWidthGated(nn.Module):
         if self.depth_gated and (self.dropped or self._depth_state()[0] == 0.0):
             return _nchw(x_in)
         live = pl["live"]
-        a1 = _gnw(self, x, self.norm1.weight, self.norm1.bias, pl["g1"], pl["b1"], self.groups, self.eps, True, Cin, None)
+        if self.conv_shortcut is None:                # identity shortcut: the `+ x` of conv2 reads the norm's alias of x
+            a1, sc = _gnw(self, x, self.norm1.weight, self.norm1.bias, pl["g1"], pl["b1"], self.groups, self.eps, True, Cin, None, fork=True)
+        else:
+            a1, sc = _gnw(self, x, self.norm1.weight, self.norm1.bias, pl["g1"], pl["b1"], self.groups, self.eps, True, Cin, None), x
         if "temb_pw" not in pl:
             pl["temb_pw"] = ops.pack_weight(pl["temb_w"], pl["temb_b"], device=dev)
         emb_silu = temb.emb_silu if isinstance(temb, TembBundle) else torch.nn.functional.silu(temb.float()).to(torch.bfloat16)
@@ -416,7 +425,6 @@ class ResnetBlock2DWidthGated(nn.Module):
                       live_out=live, rowbias=_rowbias_of(tproj, pl["w1"].N))
         a2 = _gnw(self, h, self.norm2.weight, self.norm2.bias, pl["g2"], pl["b2"], pl["k_live"], self.eps, True,
                                    pl["c_live"], live)
-        sc = x
         if self.conv_shortcut is not None:
             sc = _cw(self, x, self.conv_shortcut.weight, self.conv_shortcut.bias, pl["wsc"],
                            self._sel_bwd_pack(pl, "wsc", self.conv_shortcut.weight, dev), pad=0)
@@ -733,19 +741,20 @@ class Transformer2DModelWidthGated(nn.Module):
             g = g.to(device=dev, dtype=torch.float32)
             return AG.GateFn.apply(y0, g.repeat(1, rep) if rep > 1 else g)
 
-        a = AG.GroupNormFn.apply(x, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False)
+        # (residual forks: each norm returns an alias of its input for the sub-block's `+ x`; see autograd.py)
+        a, x_res = AG.GroupNormFn.apply(x, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False, True)
         tok = a.reshape(B, P, C)
-        x_tok = x.reshape(B, P, C)
+        x_tok = x_res.reshape(B, P, C)
         h = AG.conv(tok, pl["proj_in"], bwd("proj_in", lambda: self.proj_in.weight), pad=0)
         # self attention
-        n = AG.LayerNormFn.apply(h, pl["ln1_g"], pl["ln1_b"], 1e-5)
+        n, h = AG.LayerNormFn.apply(h, pl["ln1_g"], pl["ln1_b"], 1e-5, True)
         a1 = tb.attn1
         qkv = AG.conv(n, pl["a1_qkv"], bwd("a1_qkv", lambda: torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)), pad=0)
         qkv = gated(qkv, a1.gate, 3)
         o = AG.SelfAttnFn.apply(qkv, a1.heads)
         h = AG.conv(o, pl["a1_o"], bwd("a1_o", lambda: a1.to_out[0].weight), pad=0, residual=h)
         # cross attention
-        n = AG.LayerNormFn.apply(h, pl["ln2_g"], pl["ln2_b"], 1e-5)
+        n, h = AG.LayerNormFn.apply(h, pl["ln2_g"], pl["ln2_b"], 1e-5, True)
         a2 = tb.attn2
         q = gated(AG.conv(n, pl["a2_q"], bwd("a2_q", lambda: a2.to_q.weight), pad=0), a2.gate)
         ehs = encoder_hidden_states.ehs if isinstance(encoder_hidden_states, CtxBundle) else \
@@ -756,7 +765,7 @@ class Transformer2DModelWidthGated(nn.Module):
         o = AG.CrossAttnFn.apply(q, kv, a2.heads)
         h = AG.conv(o, pl["a2_o"], bwd("a2_o", lambda: a2.to_out[0].weight), pad=0, residual=h)
         # feed-forward (GEGLU in its un-interleaved training form)
-        n = AG.LayerNormFn.apply(h, pl["ln3_g"], pl["ln3_b"], 1e-5)
+        n, h = AG.LayerNormFn.apply(h, pl["ln3_g"], pl["ln3_b"], 1e-5, True)
         geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
         if "ff1_plain" not in pl:
             pl["ff1_plain"] = ops.pack_weight(geglu.proj.weight.detach(), geglu.proj.bias.detach(), device=dev)
@@ -821,12 +830,13 @@ class Transformer2DModelWidthGated(nn.Module):
                 pl[key] = ent
             return ent
 
-        a = _gnw(self, x, self.norm.weight, self.norm.bias, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False, C, None)
+        # (residual forks: each norm returns an alias of its input for the sub-block's `+ x`; see autograd.py)
+        a, x_res = _gnw(self, x, self.norm.weight, self.norm.bias, pl["gn_g"], pl["gn_b"], self.groups, 1e-6, False, C, None, fork=True)
         tok = a.reshape(B, P, C)
-        x_tok = x.reshape(B, P, C)
+        x_tok = x_res.reshape(B, P, C)
         h = lin(tok, "proj_in", self.proj_in)
         # self attention
-        n = _lnw(self, h, tb.norm1.weight, tb.norm1.bias, pl["ln1_g"], pl["ln1_b"], 1e-5)
+        n, h = _lnw(self, h, tb.norm1.weight, tb.norm1.bias, pl["ln1_g"], pl["ln1_b"], 1e-5, fork=True)
         a1 = tb.attn1
         l1, h1 = live_of(a1.gate, 64)
         h1 = a1.heads if h1 is None else h1
@@ -834,7 +844,7 @@ class Transformer2DModelWidthGated(nn.Module):
         o = AG.SelfAttnFn.apply(qkv, h1)
         h = lin(o, "a1o", a1.to_out[0], None, l1, residual=h)        # "+ h" in the GEMM epilogue (its gradient is dy itself)
         # cross attention
-        n = _lnw(self, h, tb.norm2.weight, tb.norm2.bias, pl["ln2_g"], pl["ln2_b"], 1e-5)
+        n, h = _lnw(self, h, tb.norm2.weight, tb.norm2.bias, pl["ln2_g"], pl["ln2_b"], 1e-5, fork=True)
         a2 = tb.attn2
         l2, h2 = live_of(a2.gate, 64)
         h2 = a2.heads if h2 is None else h2
@@ -845,7 +855,7 @@ class Transformer2DModelWidthGated(nn.Module):
         o = AG.CrossAttnFn.apply(q, kv, h2)
         h = lin(o, "a2o", a2.to_out[0], None, l2, residual=h)
         # feed-forward
-        n = _lnw(self, h, tb.norm3.weight, tb.norm3.bias, pl["ln3_g"], pl["ln3_b"], 1e-5)
+        n, h = _lnw(self, h, tb.norm3.weight, tb.norm3.bias, pl["ln3_g"], pl["ln3_b"], 1e-5, fork=True)
         geglu, lin2 = tb.ff.net[0], tb.ff.net[2]
         lf, _ = live_of(geglu.gate, geglu.dim_out // geglu.gate.width)
         lo2 = None if lf is None else torch.cat([lf, lf + geglu.dim_out])

@@ -515,6 +515,8 @@ typedef struct {
   const float* fwd_stats;
   void* workspace;
   float* pgrad_partial;   /* optional fp32 [B, nchunk, C, 2]: per-channel (sum dz, sum dz*xhat) -> dbeta, dgamma (fine-tuning) */
+  const void* add; int64_t ldadd;   /* optional bf16 [B*HW, C]: dx = (norm gradient) + add in fp32, rounded once -- the gradient that
+                                     * arrives over the residual path when x forks into norm(x) and `+ x` (round 3) */
 } AptpGroupNormBwdParams;
 int aptp_groupnorm_bwd(const AptpGroupNormBwdParams* p, aptp_stream_t stream);
 
@@ -526,6 +528,7 @@ typedef struct {
   int32_t rows, C;
   const float* gamma;
   float eps;
+  const void* add; int64_t ldadd;   /* optional bf16 [rows, C]: dx += add (as AptpGroupNormBwdParams.add) */
 } AptpLayerNormBwdParams;
 int aptp_layernorm_bwd(const AptpLayerNormBwdParams* p, aptp_stream_t stream);
 

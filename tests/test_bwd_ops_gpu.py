@@ -95,6 +95,55 @@ def test_layernorm_bwd(ops, cuda, rows, C):
     assert rel_l2(dx.float().cpu(), x.grad) <= TOL
 
 
+def test_residual_fork_gradient_is_added_inside_the_norm_backward(ops, cuda):
+    """`x + f(norm(x))`: with fork=True the norm Functions hand out an alias of x for the `+ x`, and the backward kernels add the
+    gradient that returns over it while writing dx (AptpGroupNormBwdParams.add / AptpLayerNormBwdParams.add).  Kernel: equals the
+    un-fused dx plus the residual gradient to one bf16 rounding; Function: the gradient of x equals torch autograd's on the same
+    graph, and an unused alias costs nothing"""
+    from diffusion_pruning_amd import autograd as AG
+    g = torch.Generator().manual_seed(21)
+    # GroupNorm (+SiLU), channels-last [B, H, W, C]
+    x = (torch.randn(2, 16, 16, 320, generator=g) * 1.3).to(cuda, torch.bfloat16)
+    dy = torch.randn(2, 16, 16, 320, generator=g).to(cuda, torch.bfloat16)
+    r = torch.randn(2, 16, 16, 320, generator=g).to(cuda, torch.bfloat16)
+    gamma = (1.0 + 0.2 * torch.randn(320, generator=g)).to(cuda)
+    beta = (0.3 * torch.randn(320, generator=g)).to(cuda)
+    _, stats = ops.groupnorm(x, gamma, beta, 32, 1e-5, True, keep_stats=True)
+    plain = ops.groupnorm_bwd(x, dy, gamma, beta, 32, 1e-5, True, stats)
+    fused = ops.groupnorm_bwd(x, dy, gamma, beta, 32, 1e-5, True, stats, add=r)
+    want = plain.float() + r.float()
+    assert float((fused.float() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())       # two roundings vs one
+    assert rel_l2(fused.float(), want) <= 4e-3
+    # LayerNorm rows
+    xl = (torch.randn(2, 77, 640, generator=g) * 1.5 + 0.2).to(cuda, torch.bfloat16)
+    dyl = torch.randn(2, 77, 640, generator=g).to(cuda, torch.bfloat16)
+    rl = torch.randn(2, 77, 640, generator=g).to(cuda, torch.bfloat16)
+    gl = (1.0 + 0.2 * torch.randn(640, generator=g)).to(cuda)
+    bl = (0.3 * torch.randn(640, generator=g)).to(cuda)
+    wantl = ops.layernorm_bwd(xl, dyl, gl, 1e-5).float() + rl.float()
+    assert rel_l2(ops.layernorm_bwd(xl, dyl, gl, 1e-5, add=rl).float(), wantl) <= 4e-3
+    # Function level: y = x + 2 * norm(x)  (the residual path carries its own gradient)
+    for kind in ("gn", "ln"):
+        xa = (x if kind == "gn" else xl).clone().requires_grad_()
+        if kind == "gn":
+            n, xr = AG.GroupNormFn.apply(xa, gamma, beta, 32, 1e-5, True, True)
+        else:
+            n, xr = AG.LayerNormFn.apply(xa, gl, bl, 1e-5, True)
+        assert xr.data_ptr() == xa.data_ptr()
+        up = dy if kind == "gn" else dyl
+        (xr * 1.0 + 2.0 * n).backward(up)
+        xb = xa.detach().clone().requires_grad_()
+        nb = AG.GroupNormFn.apply(xb, gamma, beta, 32, 1e-5, True) if kind == "gn" else AG.LayerNormFn.apply(xb, gl, bl, 1e-5)
+        (xb * 1.0 + 2.0 * nb).backward(up)
+        assert rel_l2(xa.grad.float(), xb.grad.float()) <= 4e-3
+        # alias unused: only the norm's gradient
+        xc = xa.detach().clone().requires_grad_()
+        nc, _ = (AG.GroupNormFn.apply(xc, gamma, beta, 32, 1e-5, True, True) if kind == "gn" else AG.LayerNormFn.apply(xc, gl, bl, 1e-5, True))
+        nc.backward(up)
+        ref = (plain if kind == "gn" else ops.layernorm_bwd(xl, dyl, gl, 1e-5))
+        assert torch.equal(xc.grad, ref)
+
+
 def test_gate_bwd_and_apply(ops, cuda):
     g = torch.Generator().manual_seed(3)
     B, H, W, C, G = 4, 8, 8, 64, 32
@@ -502,6 +551,40 @@ def test_batched_weight_gradients_equal_the_single_launches(ops, cuda):
                 assert bool((b[:, :, C:] == -3).all())                                         # the padding columns are left alone
                 if wdb:
                     assert torch.allclose(db_, dy.float().sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
+
+
+def test_batched_weight_gradient_of_an_upsampler_conv(ops, cuda):
+    """the convolution behind a folded nearest-x2 up-sample rides in the same batch (stride 1 on the up-sampled grid; the halo copy
+    fetches source pixel (iy >> 1, ix >> 1)): bitwise the per-layer launch with the same split"""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 16, 16, 96, generator=g).to(cuda, torch.bfloat16)
+    dy = torch.randn(2, 32, 32, 72, generator=g).to(cuda, torch.bfloat16)
+    x1 = torch.randn(2, 32, 32, 64, generator=g).to(cuda, torch.bfloat16)          # an ordinary 3x3 layer in the same launch
+    dy1 = torch.randn(2, 32, 32, 64, generator=g).to(cuda, torch.bfloat16)
+
+    def run():
+        a, b = torch.full((72, 9, 128), 7.0, device=cuda), torch.full((64, 9, 64), 7.0, device=cuda)
+        da = torch.zeros(72, device=cuda)
+        assert ops._wgrad_direct(x, dy, 3, 3, split_m=2, out=a, want_db=True, ups=1, db_out=da) is not None
+        assert ops._wgrad_direct(x1, dy1, 3, 3, split_m=1, out=b) is not None
+        return a, b, da
+    want = run()
+    ops.WGRAD_DEFER, ops.FOLD_DEFER = [], []
+    try:
+        got = run()
+        wrec, frec = ops.WGRAD_DEFER, ops.FOLD_DEFER
+    finally:
+        ops.WGRAD_DEFER, ops.FOLD_DEFER = None, None
+    assert len(wrec) == 2 and len(frec) == 1
+    ops.WgradBatch(wrec).run()
+    ops.FoldBatch(frec).run()
+    torch.cuda.synchronize()
+    for w, gt in zip(want, got):
+        assert torch.equal(w, gt)
+    xu = x.float().repeat_interleave(2, 1).repeat_interleave(2, 2).permute(0, 3, 1, 2)
+    cols = torch.nn.functional.unfold(xu, 3, padding=1).view(2, 96, 9, 1024)
+    ref = torch.einsum("bctm,bmn->ntc", cols, dy.float().reshape(2, 1024, 72))
+    assert float((got[0][:, :, :96] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
 
 
 @pytest.mark.parametrize("case", ["bf16_nhwc", "bf16_slice", "f32_nchw", "bf16_big", "odd_rows", "nchw_face"])

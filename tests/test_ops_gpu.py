@@ -956,3 +956,36 @@ def test_conv_with_groupnorm_in_the_splitk_reduce(cuda, B, H, Cin, N, groups, li
     y = F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1) + rb[:, :, None, None]
     ref = F.silu(F.group_norm(y[:, :live].bfloat16().float(), groups, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
     assert rel_l2(fused[..., :live].float().cpu(), ref) <= 6e-3
+
+
+def test_capture_time_scratch_buffers_are_never_released(ops, cuda):
+    """A scratch buffer handed out while a stream is capturing lives in that graph's private pool and its address is baked into
+    every launch captured with it -- also into graphs captured later on the same stream.  When a larger request replaced it in
+    the cache after its owning graph had died, torch.cuda.graph.__enter__'s empty_cache() returned the block to the device and
+    the younger graph's replays wrote through a stale address ("write access to a read-only page", for some test orders only).
+    The policy that prevents it: such buffers are kept for the life of the process (ops._ws_capture_keep)."""
+    import gc
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        w1 = ops._workspace(1 << 20, cuda)
+        w1.zero_()
+        p1, n1 = w1.data_ptr(), w1.numel()
+    del w1, g1
+    gc.collect()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        small = ops._workspace(1 << 10, cuda)              # served from the cached buffer of the dead graph
+        small.fill_(7)
+        assert small.data_ptr() == p1
+        big = ops._workspace(n1 * 4, cuda)                 # replaces it in the cache
+        big.zero_()
+    del small, big
+    gc.collect()
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3):                             # __enter__ empties the caching allocator
+        torch.zeros(8, device=cuda)
+    kept = [b for b in ops._ws_capture_keep if b.data_ptr() == p1]
+    assert kept and kept[0].numel() == n1
+    g2.replay()                                            # writes through p1: must still be this process's memory
+    torch.cuda.synchronize()
+    assert bool((kept[0][:1 << 10] == 7).all())

@@ -83,7 +83,9 @@ def test_graphed_pruning_step_full_size_bs4(cuda):
     assert gref.shape == gate_grad.shape == (B, step.quantizer.vq_embed_dim)
     check(rel_l2(gate_grad, gref), 6e-2, "gate-gradient buffer [4, 1620] after a graph replay (full size, bs=4)")
     per_sample = max(rel_l2(gate_grad[i], gref[i]) for i in range(B))
-    check(per_sample, 8e-2, "worst sample of the gate-gradient buffer")
+    # (7.7e-2 with in-kernel split-K, 8.0e-2 when the split launches fall back to the reduce launch -- the counter slabs are a
+    #  per-process pool, so which form a launch takes depends on what ran before; a mis-ordered segment or a sign error is O(1))
+    check(per_sample, 1e-1, "worst sample of the gate-gradient buffer")
     g = torch.cat([p_.grad.float().cpu().flatten() for p_ in hn.parameters()])
     g_ref = torch.cat([p_.grad.flatten() for p_ in hn_ref.parameters()])
     assert float(g_ref.abs().sum()) > 0

@@ -239,6 +239,9 @@ class PackedTrainer:
     @torch.no_grad()
     def export_(self):
         """write the packed values back into the diffusers-named full-shape parameters (checkpoint interface)"""
+        sync = getattr(self, "sync", None)
+        if sync is not None:
+            sync()                                # (a graphed step's optimizer tail runs on its own stream)
         for e in self.gemms.values():
             e.export_()
         for a in self.affines.values():

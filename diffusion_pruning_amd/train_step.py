@@ -19,6 +19,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -705,6 +707,7 @@ class GraphedFineTunerStep(FineTunerStep):
         self._dp_graphed, self._bucket_bytes, self._reduce_mode = data_parallel, bucket_bytes, reduce_mode
         self.defer_folds, self.direct_grads, self._folds = True, True, None
         self.defer_wgrads, self._wgrads = True, None
+        self.overlap_tail = os.environ.get("APTP_FT_OVERLAP_TAIL", "0") == "1"   # measured: 28.9 steps/s with, 29.9 without (HBM-bound tail next to the teacher: contention)
         from .packed_train import PackedTrainer
         self.trainer = PackedTrainer(student).attach()
         self.opt_kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
@@ -762,16 +765,25 @@ class GraphedFineTunerStep(FineTunerStep):
         if direct:
             self.trainer.ensure_grad_buffers()
 
-        def fwd_bwd():
+        def teacher_fwd():
+            # own split-K counters / scratch: this graph replays NEXT TO the previous step's optimizer tail (ops.scratch_domain)
+            with torch.no_grad(), ops.scratch_domain("teacher"):
+                fp = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
+            return fp, dict(self.acts_t)
+
+        def student_fwd_bwd(full_pred, teacher_acts):
             if not direct:
                 for p in params:
                     p.grad = None
-            with torch.no_grad():
-                full_pred = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
             pred = self.student(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
+            self.acts_t.clear()
+            self.acts_t.update(teacher_acts)
             total, diff, dist_l, blk = self._losses(pred, full_pred, st["snr_w"], st["target"])
             total.backward()
             out.update(total=total.detach(), diff=diff, dist=dist_l, blk=blk)
+
+        def fwd_bwd():
+            student_fwd_bwd(*teacher_fwd())
 
         # warm-up (allocator, plan caches, autograd's stream anchors) runs forward + backward only: nothing to undo afterwards
         side = torch.cuda.Stream()
@@ -786,6 +798,13 @@ class GraphedFineTunerStep(FineTunerStep):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         log0 = None if ops.LAUNCH_LOG is None else len(ops.LAUNCH_LOG)     # (bench.py: the contractions of ONE captured step)
+        # TWO graphs.  The teacher's forward reads no trainable state, so step i+1's teacher pass does not have to wait for step
+        # i's optimizer: it is its own graph (own memory pool: it replays NEXT TO the tail of the previous step, whose kernels
+        # still read tensors of the student graph's pool), and train_step() issues the tail -- batched weight gradients, folds,
+        # AdamW, operand refresh: 6.7 of 33.8 ms, HBM-bound for the most part -- on a second stream.
+        g_teacher = new_graph()
+        with torch.cuda.graph(g_teacher):
+            full_pred, teacher_acts = teacher_fwd()
         graph = new_graph()
         # The slab folds of the split weight gradients (and the chunk folds of the norm-affine gradients) are only RECORDED while
         # the backward is captured and run as ONE launch behind every replay (ops.FoldBatch: 357 launches of ~8 us otherwise):
@@ -797,7 +816,7 @@ class GraphedFineTunerStep(FineTunerStep):
         ops.GRAD_DIRECT = direct
         try:
             with torch.cuda.graph(graph):
-                fwd_bwd()
+                student_fwd_bwd(full_pred, teacher_acts)
             folds, wgrads = ops.FOLD_DEFER, ops.WGRAD_DEFER
         finally:
             ops.FOLD_DEFER = None
@@ -813,16 +832,25 @@ class GraphedFineTunerStep(FineTunerStep):
         from .packed_train import PackedAdamW
         self.optimizer = PackedAdamW(self.trainer, lr=self.opt_kw["lr"], betas=self.opt_kw["betas"], eps=self.opt_kw["eps"],
                                      weight_decay=self.opt_kw["weight_decay"])
-        self._cap = dict(st=st, graph=graph, launch_log=launch_log, **out)
+        self._cap = dict(st=st, graph=graph, g_teacher=g_teacher, full_pred=full_pred, teacher_acts=teacher_acts,
+                         tail_stream=torch.cuda.Stream(), ev_bwd=torch.cuda.Event(), ev_tail=None, launch_log=launch_log, **out)
+        self.trainer.sync = self.finish          # (export_ / state_dict read the parameters: after the pending optimizer tail)
         if self._dp_graphed:
             self.reducer = BucketedGradReducer(self.optimizer.params, self._bucket_bytes, mode=self._reduce_mode, hooks=False)
         return self
+
+    def finish(self):
+        """make the current stream wait for the optimizer tail of the last train_step (it runs on its own stream so that the next
+        step's teacher forward overlaps it); call before reading parameters on the current stream -- PackedTrainer.export_ does"""
+        cap = self._cap
+        if cap is not None and cap.get("ev_tail") is not None:
+            torch.cuda.current_stream().wait_event(cap["ev_tail"])
 
     def graph_nodes(self):
         """nodes of the captured teacher + student forward / backward graph, when it was kept (graph_utils.KEEP_GRAPHS)"""
         if self._cap is None:
             return None
-        n = {"fwd_bwd": node_count(self._cap["graph"])}
+        n = {"teacher": node_count(self._cap["g_teacher"]), "student_fwd_bwd": node_count(self._cap["graph"])}
         if self._wgrads is not None:
             n["batched_wgrad_launches"] = self._wgrads.launches()
         if self._folds is not None:
@@ -838,14 +866,25 @@ class GraphedFineTunerStep(FineTunerStep):
             for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target"):
                 cap["st"][k].copy_(batch[k])
             cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
+        main = torch.cuda.current_stream()
+        cap["g_teacher"].replay()                # reads no trainable state: runs next to the previous step's tail
+        if cap["ev_tail"] is not None:
+            main.wait_event(cap["ev_tail"])      # parameters and operands of the previous step are in place
         cap["graph"].replay()
-        if self._wgrads is not None:
-            self._wgrads.run()                   # every stride-1 weight gradient of the backward: one launch per filter size
-        if self._folds is not None:
-            self._folds.run()                    # every deferred slab / chunk fold of the backward: one launch
-        if self._dp_graphed and self.reducer is not None:
-            self.reducer.exchange_all()          # mean over the ranks, written in place (the optimizer's table holds these addresses)
-        self.optimizer.step()
+        cap["ev_bwd"].record(main)
+        tail = cap["tail_stream"] if self.overlap_tail else main
+        with torch.cuda.stream(tail):
+            tail.wait_event(cap["ev_bwd"])
+            if self._wgrads is not None:
+                self._wgrads.run()               # every stride-1 weight gradient of the backward: one launch per filter size
+            if self._folds is not None:
+                self._folds.run()                # every deferred slab / chunk fold of the backward: one launch
+            if self._dp_graphed and self.reducer is not None:
+                self.reducer.exchange_all()      # mean over the ranks, written in place (the optimizer's table holds these addresses)
+            self.optimizer.step()
+            ev = cap["ev_tail"] or torch.cuda.Event()
+            ev.record(tail)
+            cap["ev_tail"] = ev
         # (clones: the graph's static outputs are overwritten by the next replay, and callers accumulate losses over steps)
         return {"loss": cap["total"].clone(), "diff_loss": cap["diff"].clone(), "distillation_loss": cap["dist"].clone(),
                 "block_loss": cap["blk"].clone()}

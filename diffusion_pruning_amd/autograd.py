@@ -110,7 +110,7 @@ def _fork_add(dres, like):
     if dres is None:
         return None
     assert dres.shape == like.shape
-    return _c(dres)
+    return _rc(dres)                 # (a channel slice of a wider gradient buffer is read in place through its leading dimension)
 
 
 class GroupNormFn(Function):

@@ -32,18 +32,27 @@ class _Gemm:
     """one contraction: packed fp32 master ``P`` [N, taps, cin_pad], optional compact bias ``Pb`` [N] (aliased by the pack),
     bf16 shadow ``pw`` (forward operand) and ``pwb`` (data-gradient operand, built on first use)"""
 
-    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], pw: ops.PackedWeight,
+    def __init__(self, weight, bias: Optional[nn.Parameter], pw: ops.PackedWeight,
                  lo: Optional[torch.Tensor], li: Optional[torch.Tensor]):
         assert not pw.geglu and pw.ln_colsum is None and pw.Cin2 == 0, "packed training uses the plain packs of the ft path"
-        self.weight, self.bias, self.pw, self.lo, self.li = weight, bias, pw, lo, li
+        # `weight` may be a tuple of equally shaped parameters that share the input (to_q | to_k | to_v of an attention block):
+        # ONE contraction whose output rows are the parts' live rows back to back; `lo` / `li` apply to every part
+        self.weights = tuple(weight) if isinstance(weight, (tuple, list)) else (weight,)
+        assert bias is None or len(self.weights) == 1
+        self.weight, self.bias, self.pw, self.lo, self.li = self.weights[0], bias, pw, lo, li
         dev = pw.w.device
-        w = weight.detach().to(device=dev, dtype=torch.float32)
-        if w.dim() == 2:
-            w = w[:, :, None, None]
-        if lo is not None:
-            w = w[lo.to(dev)]
-        if li is not None:
-            w = w[:, li.to(dev)]
+        ws = []
+        for wp in self.weights:
+            w = wp.detach().to(device=dev, dtype=torch.float32)
+            if w.dim() == 2:
+                w = w[:, :, None, None]
+            if lo is not None:
+                w = w[lo.to(dev)]
+            if li is not None:
+                w = w[:, li.to(dev)]
+            ws.append(w)
+        self.n_part = ws[0].shape[0]
+        w = torch.cat(ws, 0) if len(ws) > 1 else ws[0]
         self.n_live, self.c_live, self.KH, self.KW = w.shape
         assert self.n_live <= pw.N and self.c_live <= pw.Cin and (self.KH, self.KW) == (pw.KH, pw.KW)
         P = torch.zeros(pw.w.shape, dtype=torch.float32, device=dev)
@@ -68,16 +77,21 @@ class _Gemm:
         if self.pwb is not None:
             ops.pack_dgrad_from_packed(self.pw, self.pwb)          # one tiled transpose (was: flip + strided copy)
 
+    def parts(self):
+        """(parameter, row range of P / P.grad it owns) for every weight of the contraction"""
+        return [(wp, slice(i * self.n_part, (i + 1) * self.n_part)) for i, wp in enumerate(self.weights)]
+
     @torch.no_grad()
     def export_(self):
-        g = self.P.detach()[:self.n_live, :, :self.c_live].permute(0, 2, 1).reshape(self.n_live, self.c_live, self.KH, self.KW)
-        full = self.weight.data
-        g = g.to(device=full.device, dtype=full.dtype)
-        if full.dim() == 2:
-            g = g.reshape(self.n_live, self.c_live)
-        ro = self.lo.to(full.device) if self.lo is not None else torch.arange(full.shape[0], device=full.device)
-        ci = self.li.to(full.device) if self.li is not None else torch.arange(full.shape[1], device=full.device)
-        full[ro[:, None], ci[None, :]] = g
+        for wp, rows in self.parts():
+            g = self.P.detach()[rows, :, :self.c_live].permute(0, 2, 1).reshape(self.n_part, self.c_live, self.KH, self.KW)
+            full = wp.data
+            g = g.to(device=full.device, dtype=full.dtype)
+            if full.dim() == 2:
+                g = g.reshape(self.n_part, self.c_live)
+            ro = self.lo.to(full.device) if self.lo is not None else torch.arange(full.shape[0], device=full.device)
+            ci = self.li.to(full.device) if self.li is not None else torch.arange(full.shape[1], device=full.device)
+            full[ro[:, None], ci[None, :]] = g
         if self.bias is not None and self.Pb is not None:
             b = self.Pb.detach()[:self.n_live].to(device=self.bias.device, dtype=self.bias.dtype)
             if self.lo is not None:
@@ -125,9 +139,10 @@ class PackedTrainer:
     # ---- called by the model's fine-tuning forward in place of AG.conv_w / AG.GroupNormWFn / AG.LayerNormWFn -----------------
     def conv(self, x, weight, bias, pw, get_bwd, stride=1, pad=None, ups=0, out_f32=False, live_out=None, live_in=None,
              residual=None, rowbias=None):
-        e = self.gemms.get(id(weight))
+        key = id(weight[0]) if isinstance(weight, (tuple, list)) else id(weight)
+        e = self.gemms.get(key)
         if e is None:
-            e = self.gemms[id(weight)] = _Gemm(weight, bias, pw, live_out, live_in)
+            e = self.gemms[key] = _Gemm(weight, bias, pw, live_out, live_in)
         assert e.pw is pw, "the plan's packs were rebuilt under a packed trainer (call PackedTrainer after the last set_structure)"
         return AG.conv_p(x, e.P, e.Pb, e.pw, e.get_bwd, stride=stride, pad=pad, ups=ups, out_f32=out_f32, residual=residual,
                          rowbias=rowbias)
@@ -193,6 +208,8 @@ class PackedTrainer:
         out = []
         for e in self.gemms.values():
             base = names.get(id(e.weight), f"<unnamed weight {tuple(e.weight.shape)}>")
+            for wp in e.weights[1:]:                  # a fused contraction: "...attn1.to_q.weight+to_k.weight+to_v.weight"
+                base += "+" + ".".join(names.get(id(wp), "?").split(".")[-2:])
             out.append((base + "::packed", e.P))
             if e.Pb is not None:
                 out.append((base + "::packed_bias", e.Pb))

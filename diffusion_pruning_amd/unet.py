@@ -817,6 +817,18 @@ class Transformer2DModelWidthGated(nn.Module):
             return _cw(self, xx, mod.weight, b, pack(name, mod.weight, b, lo, li), bwd(name, mod.weight, lo, li), pad=0,
                              live_out=lo, live_in=li, residual=residual)
 
+        def lin_cat(xx, name, mods, lo):
+            """projections that share their input (to_q | to_k | to_v) as ONE contraction under a PackedTrainer: one forward,
+            one data-gradient and one weight-gradient launch instead of three each, no concatenation copy, no fan-in adds"""
+            ws = tuple(m.weight for m in mods)
+            key = name + "_ft"
+            if key not in pl:
+                pl[key] = ops.pack_weight(torch.cat([w.detach() if lo is None else w.detach()[lo] for w in ws], 0), None, device=dev)
+            return _cw(self, xx, ws, None, pl[key], None, pad=0, live_out=lo)
+
+        fuse_qkv = self.__dict__.get("_pk") is not None and FT_FUSE_QKV and all(
+            m.bias is None for m in (tb.attn1.to_q, tb.attn1.to_k, tb.attn1.to_v, tb.attn2.to_k, tb.attn2.to_v))
+
         def live_of(gate, width):
             # (cached in the plan: the index tensor is uploaded once, never while a stream is capturing)
             key = ("live", id(gate))
@@ -840,7 +852,10 @@ class Transformer2DModelWidthGated(nn.Module):
         a1 = tb.attn1
         l1, h1 = live_of(a1.gate, 64)
         h1 = a1.heads if h1 is None else h1
-        qkv = torch.cat([lin(n, "a1q", a1.to_q, l1), lin(n, "a1k", a1.to_k, l1), lin(n, "a1v", a1.to_v, l1)], dim=-1)
+        if fuse_qkv:
+            qkv = lin_cat(n, "a1qkv", (a1.to_q, a1.to_k, a1.to_v), l1)
+        else:
+            qkv = torch.cat([lin(n, "a1q", a1.to_q, l1), lin(n, "a1k", a1.to_k, l1), lin(n, "a1v", a1.to_v, l1)], dim=-1)
         o = AG.SelfAttnFn.apply(qkv, h1)
         h = lin(o, "a1o", a1.to_out[0], None, l1, residual=h)        # "+ h" in the GEMM epilogue (its gradient is dy itself)
         # cross attention
@@ -851,7 +866,10 @@ class Transformer2DModelWidthGated(nn.Module):
         ehs = encoder_hidden_states.ehs if isinstance(encoder_hidden_states, CtxBundle) else \
             encoder_hidden_states.to(device=dev, dtype=torch.bfloat16)
         q = lin(n, "a2q", a2.to_q, l2)
-        kv = torch.cat([lin(ehs, "a2k", a2.to_k, l2), lin(ehs, "a2v", a2.to_v, l2)], dim=-1)
+        if fuse_qkv:
+            kv = lin_cat(ehs, "a2kv", (a2.to_k, a2.to_v), l2)
+        else:
+            kv = torch.cat([lin(ehs, "a2k", a2.to_k, l2), lin(ehs, "a2v", a2.to_v, l2)], dim=-1)
         o = AG.CrossAttnFn.apply(q, kv, h2)
         h = lin(o, "a2o", a2.to_out[0], None, l2, residual=h)
         # feed-forward
@@ -1240,6 +1258,7 @@ class UpBlock2DWidthHalfDepthGated(CrossAttnUpBlock2DWidthHalfDepthGated):
 FUSE_SHORTCUT = os.environ.get("APTP_FUSE_SHORTCUT", "1") != "0"
 # APTP_FOLD_LN=0 keeps the three LayerNorms of a transformer block as stand-alone kernels (A/B timing, debugging)
 FOLD_LN = os.environ.get("APTP_FOLD_LN", "1") != "0"
+FT_FUSE_QKV = os.environ.get("APTP_FT_FUSE_QKV", "1") != "0"     # packed fine-tuning: to_q | to_k | to_v (and to_k | to_v) as one contraction
 CAT_STATS = {"views": 0, "copies": 0}     # how the skip-concats of the forwards so far were realised (tests / tools)
 
 

@@ -104,10 +104,14 @@ def _two_students(cuda, mask):
     return cfg, a, b, teacher
 
 
-def test_packed_masters_train_like_diffusers_layout_masters(cuda):
+@pytest.mark.parametrize("fuse_qkv", [False, True])
+def test_packed_masters_train_like_diffusers_layout_masters(cuda, monkeypatch, fuse_qkv):
     """packed_train.PackedTrainer: the optimizer owns compact fp32 tensors in the kernels' order; one SGD step on them, written
     back with export_(), equals one SGD step on the diffusers-layout masters (same kernels produce the gradients; only the
-    scatter into full-shape tensors and the re-pack disappear)"""
+    scatter into full-shape tensors and the re-pack disappear).  With to_q | to_k | to_v as ONE packed contraction
+    (unet.FT_FUSE_QKV) the launches differ in shape, so the comparison is to accumulation-order accuracy instead of bitwise."""
+    from diffusion_pruning_amd import unet as unet_mod
+    monkeypatch.setattr(unet_mod, "FT_FUSE_QKV", fuse_qkv)
     from diffusion_pruning_amd.packed_train import PackedTrainer
     from diffusion_pruning_amd.train_step import FineTunerStep, synthetic_batch
     mask = O.random_mask(O.TINY, 0.5, 8, n_depth_off=1)
@@ -123,14 +127,15 @@ def test_packed_masters_train_like_diffusers_layout_masters(cuda):
     assert n_pk < 0.8 * n_full                        # dead channels / heads / chunks / the dropped block carry no state
     opt_b = torch.optim.SGD(pk.parameters(), lr=1e-2)
     lb = float(step_b.train_step(opt_b, batch)["loss"].detach())
-    assert abs(la - lb) <= 1e-5 * abs(la)
+    assert abs(la - lb) <= (2e-3 if fuse_qkv else 1e-5) * abs(la)
     pk.export_()
     worst = 0.0
     for (na, pa), (nb, pb) in zip(sa.named_parameters(), sb.named_parameters()):
         assert na == nb
         d = float((pa.detach() - pb.detach()).abs().max())
         worst = max(worst, d / (float(pa.detach().abs().max()) + 1e-12))
-    check(worst, 1e-5, "max relative parameter difference after one SGD step (packed vs diffusers-layout masters)")
+    check(worst, 2e-3 if fuse_qkv else 1e-5, "max relative parameter difference after one SGD step (packed vs diffusers-layout masters%s)"
+          % (", fused qkv" if fuse_qkv else ""))
     # the second forward runs on the refreshed shadows: same loss as the reference path's second step
     la2 = float(step_a.train_step(opt_a, batch)["loss"].detach())
     lb2 = float(step_b.train_step(opt_b, batch)["loss"].detach())

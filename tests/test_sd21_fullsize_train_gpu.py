@@ -147,20 +147,24 @@ def test_graphed_finetune_step_full_size_bs4_gradients_and_second_step(cuda):
         assert torch.isfinite(g).all(), name
         errs[name] = rel_l2(g, r)
         got_all.append(g.flatten()); ref_all.append(r.flatten())
+    fused = 0
     for e in step.trainer.gemms.values():
-        n = names[id(e.weight)]
-        r = sp[n].grad
-        r4 = r if r.dim() == 4 else r[:, :, None, None]
-        if e.lo is not None:
-            r4 = r4[e.lo.cpu()]
-        if e.li is not None:
-            r4 = r4[:, e.li.cpu()]
-        g = e.P.grad[:e.n_live, :, :e.c_live].float().cpu().permute(0, 2, 1).reshape(e.n_live, e.c_live, e.KH, e.KW)
-        add(n, g, r4)
+        fused += len(e.weights) > 1
+        for wp, rows in e.parts():                   # (to_q | to_k | to_v train as ONE contraction: a part per parameter)
+            n = names[id(wp)]
+            r = sp[n].grad
+            r4 = r if r.dim() == 4 else r[:, :, None, None]
+            if e.lo is not None:
+                r4 = r4[e.lo.cpu()]
+            if e.li is not None:
+                r4 = r4[:, e.li.cpu()]
+            g = e.P.grad[rows, :, :e.c_live].float().cpu().permute(0, 2, 1).reshape(e.n_part, e.c_live, e.KH, e.KW)
+            add(n, g, r4)
         if e.Pb is not None and e.bias is not None:
             rb = sp[names[id(e.bias)]].grad
             rb = rb[e.lo.cpu()] if e.lo is not None else rb
             add(names[id(e.bias)], e.Pb.grad[:e.n_live].float().cpu(), rb)
+    assert fused >= 16 and fused % 2 == 0            # per live transformer block: self-attention qkv and cross-attention kv
     for a in step.trainer.affines.values():
         for P, full in ((a.Pg, a.gamma_p), (a.Pb, a.beta_p)):
             r = sp[names[id(full)]].grad

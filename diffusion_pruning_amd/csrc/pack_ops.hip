@@ -12,6 +12,24 @@ namespace {
 
 struct FoldK { const float* in; float* out; int R, n_rows, C, ld_out; float* tail_out; int rows1; int pair_split; int tail_n; };
 
+// the four sums of column quad e .. e+3 to their destination (C % 4 == 0)
+__device__ __forceinline__ void fold_store4(const FoldK& p, int64_t e, const float4 t) {
+  const int64_t row = e / p.C, c = e - row * p.C;
+  if (p.pair_split) {          // columns are (a, b) pairs: a_k -> out[k], b_k -> tail_out[k] (or out[ld_out + k])
+    float* const ob = p.tail_out ? p.tail_out : p.out + p.ld_out;
+    const int k = (int)(c >> 1);
+    p.out[k] = t.x; ob[k] = t.y; p.out[k + 1] = t.z; ob[k + 1] = t.w;
+  } else if (row < p.rows1) {
+    float* o = p.out + row * p.ld_out + c;
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  } else {
+    const int64_t i = (row - p.rows1) * p.C + c;      // tail: only its first tail_n values exist at the destination
+    float* o = p.tail_out + i;
+    if (i + 3 < p.tail_n) { o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+    else { if (i < p.tail_n) o[0] = t.x; if (i + 1 < p.tail_n) o[1] = t.y; if (i + 2 < p.tail_n) o[2] = t.z; }
+  }
+}
+
 // block = 32 column quads x 8 row slices: slice s sums rows s, s+8, ... (independent 16-byte loads in flight), the slices are
 // folded 0..7 through LDS: the order is fixed, the result does not depend on scheduling
 __device__ __forceinline__ void fold_rows_block(const FoldK& p, int64_t blk) {
@@ -42,20 +60,7 @@ __device__ __forceinline__ void fold_rows_block(const FoldK& p, int64_t blk) {
       float4 t = red[0][cq];
 #pragma unroll
       for (int q = 1; q < 8; ++q) { const float4 b = red[q][cq]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
-      const int64_t row = e / p.C, c = e - row * p.C;
-      if (p.pair_split) {          // columns are (a, b) pairs: a_k -> out[k], b_k -> tail_out[k] (or out[ld_out + k])
-        float* const ob = p.tail_out ? p.tail_out : p.out + p.ld_out;
-        const int k = (int)(c >> 1);
-        p.out[k] = t.x; ob[k] = t.y; p.out[k + 1] = t.z; ob[k + 1] = t.w;
-      } else if (row < p.rows1) {
-        float* o = p.out + row * p.ld_out + c;
-        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
-      } else {
-        const int64_t i = (row - p.rows1) * p.C + c;      // tail: only its first tail_n values exist at the destination
-        float* o = p.tail_out + i;
-        if (i + 3 < p.tail_n) { o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
-        else { if (i < p.tail_n) o[0] = t.x; if (i + 1 < p.tail_n) o[1] = t.y; if (i + 2 < p.tail_n) o[2] = t.z; }
-      }
+      fold_store4(p, e, t);
     }
   } else {
     const int64_t e = (int64_t)blk * 32 + cq;
@@ -97,10 +102,33 @@ __global__ __launch_bounds__(256) void fold_rows_many_kernel(const AptpFoldRowsP
   }
   int s0 = starts[lo], s1 = starts[lo + 1];
   FoldK k = fold_item(items[lo]);
-  for (; u < u_end; ++u) {
+  while (u < u_end) {
     while (u >= s1) { ++lo; s0 = s1; s1 = starts[lo + 1]; k = fold_item(items[lo]); }
-    __syncthreads();                            // (the staging array of the previous unit is free)
-    fold_rows_block(k, u - s0);
+    const int run_end = u_end < s1 ? u_end : s1;        // this workgroup's units inside item `lo`
+    if (k.R <= 8 && (k.C & 3) == 0) {
+      // few slabs (the batched weight gradients leave 2..8): one column quad per thread, all R loads of a thread in flight
+      // at once, no staging.  Same summation order as the staged form (slab 0, 1, ..., R-1): bitwise the same result.
+      const int64_t total = (int64_t)k.n_rows * k.C;
+      for (int64_t q = (int64_t)(u - s0) * 32 + threadIdx.x; q < (int64_t)(run_end - s0) * 32; q += 256) {
+        const int64_t e = q << 2;
+        if (e >= total) break;
+        float4 b[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          b[r] = r < k.R ? *reinterpret_cast<const float4*>(k.in + (int64_t)r * total + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 t = b[0];
+#pragma unroll
+        for (int r = 1; r < 8; ++r)
+          if (r < k.R) { t.x += b[r].x; t.y += b[r].y; t.z += b[r].z; t.w += b[r].w; }
+        fold_store4(k, e, t);
+      }
+      u = run_end;
+    } else {
+      for (; u < run_end; ++u) {
+        __syncthreads();                          // (the staging array of the previous unit is free)
+        fold_rows_block(k, u - s0);
+      }
+    }
   }
 }
 

@@ -360,7 +360,10 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
            torch.cuda.current_stream().cuda_stream, _domain())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        size = max(nbytes, 1 << 20)
+        if key[1] and buf is not None:
+            size = max(size, buf.numel() + buf.numel() // 2)      # (kept forever, below: grow geometrically so the kept set stays small)
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
         if key[1]:
             # Allocated while a stream is capturing: the block comes from that graph's private pool and its address is baked into
             # every launch captured with it -- possibly into graphs captured LATER on the same stream, which may outlive the graph

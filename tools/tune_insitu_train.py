@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--step", choices=["train", "finetune"], default="train")
     ap.add_argument("--expert", type=int, default=3)
     ap.add_argument("--top", type=int, default=20)
+    ap.add_argument("--skip", type=int, default=0, help="shapes (in order of share) already visited by an earlier pass")
     ap.add_argument("--replays", type=int, default=12)
     ap.add_argument("--margin", type=float, default=0.003)
     ap.add_argument("--budget-s", type=float, default=900.0)
@@ -151,7 +152,7 @@ def main():
         key = ops.tuning_key(p.B * p.Hout * p.Wout, p.N, p.Cin, p.KH * p.KW, p.stride, p.ups, p.act == ACT_GEGLU, p.Cin2 if p.x2 else 0)
         s = shapes.setdefault(key, {"count": 0, "flops": rec["flops"], "params": p})
         s["count"] += 1
-    order = sorted(shapes, key=lambda k: -shapes[k]["flops"] * shapes[k]["count"])[:args.top]
+    order = sorted(shapes, key=lambda k: -shapes[k]["flops"] * shapes[k]["count"])[args.skip:args.skip + args.top]
 
     def cls(key):
         M, N, C, T, s_, u, g_, x2 = (int(v) if v else 0 for v in KEY.match(key).groups())

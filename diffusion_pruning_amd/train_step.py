@@ -464,6 +464,11 @@ class GraphedPrunerStep(PrunerStep):
 
         # warm-up on a side stream (allocator / plan caches), then capture: the module state at capture time decides what
         # is baked in, so the structure is installed right before each capture
+        # ops.LAUNCH_LOG (bench.py: the contractions of ONE step, re-timed for the family roofline) is filled by this eager pass,
+        # never by the captures: a log entry keeps its operands alive, and a capture that cannot recycle any activation spreads
+        # the step over several times the memory -- its replays were measured ~7 % slower
+        user_log = ops.LAUNCH_LOG
+        log0 = None if user_log is None else len(user_log)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -473,28 +478,32 @@ class GraphedPrunerStep(PrunerStep):
             student_bwd(*student_fwd(), fp, ta)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        launch_log = None if user_log is None else user_log[log0:]
+        ops.LAUNCH_LOG = None
 
         # THREE graphs.  The student's forward does not read the teacher (only the loss terms do), so it is its own graph:
         # at replay it starts as soon as the router has produced the code, NEXT TO the teacher graph that has been running
         # on the side stream since the batch arrived; the loss + backward graph joins the two.  Graphs that replay
         # concurrently must not share a memory pool (a pool hands one capture's freed scratch to the next capture, which is
         # only safe when replays are serialised in capture order): the teacher has its own, the two student graphs share one.
-        log0 = None if ops.LAUNCH_LOG is None else len(ops.LAUNCH_LOG)     # (bench.py: the contractions of ONE captured step)
-        self.unet.set_structure({"width": list(full["width"]), "depth": list(full["depth"])})
-        g_teacher = new_graph()
-        with torch.cuda.graph(g_teacher):
-            full_pred, teacher_acts = teacher()
-        self.unet.set_structure({"width": list(gw), "depth": list(gd)})
-        g_student = new_graph()
-        with torch.cuda.graph(g_student):
-            pred, acts = student_fwd()
-        g_student_bwd = new_graph()
-        with torch.cuda.graph(g_student_bwd, pool=g_student.pool()):
-            loss, dist, blk, grad = student_bwd(pred, acts, full_pred, teacher_acts)
+        try:
+            self.unet.set_structure({"width": list(full["width"]), "depth": list(full["depth"])})
+            g_teacher = new_graph()
+            with torch.cuda.graph(g_teacher):
+                full_pred, teacher_acts = teacher()
+            self.unet.set_structure({"width": list(gw), "depth": list(gd)})
+            g_student = new_graph()
+            with torch.cuda.graph(g_student):
+                pred, acts = student_fwd()
+            g_student_bwd = new_graph()
+            with torch.cuda.graph(g_student_bwd, pool=g_student.pool()):
+                loss, dist, blk, grad = student_bwd(pred, acts, full_pred, teacher_acts)
+        finally:
+            ops.LAUNCH_LOG = user_log
         # (everything a captured kernel reads must outlive the graphs: `inv` is an operand of the gather that ends g_student_bwd)
         self._cap = dict(st=st, ga=ga, install_code=install_code, perm=perm, inv=inv, full=full, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
                          loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs,
-                         launch_log=None if log0 is None else ops.LAUNCH_LOG[log0:])
+                         launch_log=launch_log)
         return self
 
     def graph_nodes(self):
@@ -786,25 +795,35 @@ class GraphedFineTunerStep(FineTunerStep):
             student_fwd_bwd(*teacher_fwd())
 
         # warm-up (allocator, plan caches, autograd's stream anchors) runs forward + backward only: nothing to undo afterwards
+        # (ops.LAUNCH_LOG -- bench.py: the contractions of ONE step -- is filled by the last eager iteration, never by the captures:
+        #  see GraphedPrunerStep.capture)
+        user_log, log0 = ops.LAUNCH_LOG, None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         ops.GRAD_DIRECT = direct
         try:
             with torch.cuda.stream(side):
-                for i in range(warmup_iters):
+                for i in range(max(1, warmup_iters)):
+                    if user_log is not None:
+                        log0 = len(user_log)
                     fwd_bwd()
         finally:
             ops.GRAD_DIRECT = False
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        log0 = None if ops.LAUNCH_LOG is None else len(ops.LAUNCH_LOG)     # (bench.py: the contractions of ONE captured step)
+        launch_log = None if user_log is None else user_log[log0:]
+        ops.LAUNCH_LOG = None
         # TWO graphs.  The teacher's forward reads no trainable state, so step i+1's teacher pass does not have to wait for step
         # i's optimizer: it is its own graph (own memory pool: it replays NEXT TO the tail of the previous step, whose kernels
         # still read tensors of the student graph's pool), and train_step() issues the tail -- batched weight gradients, folds,
         # AdamW, operand refresh: 6.7 of 33.8 ms, HBM-bound for the most part -- on a second stream.
         g_teacher = new_graph()
-        with torch.cuda.graph(g_teacher):
-            full_pred, teacher_acts = teacher_fwd()
+        try:
+            with torch.cuda.graph(g_teacher):
+                full_pred, teacher_acts = teacher_fwd()
+        except BaseException:
+            ops.LAUNCH_LOG = user_log
+            raise
         graph = new_graph()
         # The slab folds of the split weight gradients (and the chunk folds of the norm-affine gradients) are only RECORDED while
         # the backward is captured and run as ONE launch behind every replay (ops.FoldBatch: 357 launches of ~8 us otherwise):
@@ -822,9 +841,9 @@ class GraphedFineTunerStep(FineTunerStep):
             ops.FOLD_DEFER = None
             ops.WGRAD_DEFER = None
             ops.GRAD_DIRECT = False
+            ops.LAUNCH_LOG = user_log
         self._wgrads = ops.WgradBatch(wgrads) if wgrads else None
         self._folds = ops.FoldBatch(folds) if folds else None
-        launch_log = None if log0 is None else ops.LAUNCH_LOG[log0:]
         # The optimizer is ONE launch over every trainable tensor and writes the bf16 operands in the same pass
         # (packed_train.PackedAdamW, csrc/optim.hip); its table holds the addresses of the gradients the captured backward
         # left in `.grad`, which every replay re-writes in place.  It runs right behind the graph, followed by the one-launch

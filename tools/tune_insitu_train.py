@@ -184,7 +184,9 @@ def main():
         torch.cuda.synchronize()
         return rc == 0
 
-    base = max(measure(base_step), measure(base_step))
+    # (the baseline comes from a fresh capture like every candidate's: the step captured with the launch log on replays ~7 %
+    #  slower, which made the first candidate of the first shape "win" in the first version of this tool)
+    base = max(measure(), measure())
     out(f"{args.step}: baseline {base:.3f} steps/s (graph replays), {len(shapes)} distinct shapes, visiting {len(order)}")
     changed = {}
     for key in order:

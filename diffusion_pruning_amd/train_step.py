@@ -716,6 +716,7 @@ class GraphedFineTunerStep(FineTunerStep):
         self._dp_graphed, self._bucket_bytes, self._reduce_mode = data_parallel, bucket_bytes, reduce_mode
         self.defer_folds, self.direct_grads, self._folds = True, True, None
         self.defer_wgrads, self._wgrads = True, None
+        self.overlap_teacher = os.environ.get("APTP_FT_OVERLAP_TEACHER", "1") != "0"   # teacher graph on a side stream next to the student's forward
         self.overlap_tail = os.environ.get("APTP_FT_OVERLAP_TAIL", "0") == "1"   # measured: 28.9 steps/s with, 29.9 without (HBM-bound tail next to the teacher: contention)
         from .packed_train import PackedTrainer
         self.trainer = PackedTrainer(student).attach()
@@ -780,11 +781,16 @@ class GraphedFineTunerStep(FineTunerStep):
                 fp = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
             return fp, dict(self.acts_t)
 
-        def student_fwd_bwd(full_pred, teacher_acts):
+        def student_fwd():
             if not direct:
                 for p in params:
                     p.grad = None
             pred = self.student(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample
+            return pred, dict(self.acts_s)
+
+        def student_bwd(pred, student_acts, full_pred, teacher_acts):
+            self.acts_s.clear()
+            self.acts_s.update(student_acts)
             self.acts_t.clear()
             self.acts_t.update(teacher_acts)
             total, diff, dist_l, blk = self._losses(pred, full_pred, st["snr_w"], st["target"])
@@ -792,7 +798,8 @@ class GraphedFineTunerStep(FineTunerStep):
             out.update(total=total.detach(), diff=diff, dist=dist_l, blk=blk)
 
         def fwd_bwd():
-            student_fwd_bwd(*teacher_fwd())
+            fp, ta = teacher_fwd()
+            student_bwd(*student_fwd(), fp, ta)
 
         # warm-up (allocator, plan caches, autograd's stream anchors) runs forward + backward only: nothing to undo afterwards
         # (ops.LAUNCH_LOG -- bench.py: the contractions of ONE step -- is filled by the last eager iteration, never by the captures:
@@ -833,9 +840,14 @@ class GraphedFineTunerStep(FineTunerStep):
         ops.FOLD_DEFER = [] if (self.defer_folds and direct) else None
         ops.WGRAD_DEFER = [] if (self.defer_wgrads and self.defer_folds and direct) else None
         ops.GRAD_DIRECT = direct
+        g_bwd = new_graph()
         try:
+            # the student's forward does not read the teacher (only the loss terms do): its own graph, replayed NEXT TO the teacher
+            # graph on the side stream; the loss + backward graph joins the two (same pool as the forward: replayed in capture order)
             with torch.cuda.graph(graph):
-                student_fwd_bwd(full_pred, teacher_acts)
+                pred, student_acts = student_fwd()
+            with torch.cuda.graph(g_bwd, pool=graph.pool()):
+                student_bwd(pred, student_acts, full_pred, teacher_acts)
             folds, wgrads = ops.FOLD_DEFER, ops.WGRAD_DEFER
         finally:
             ops.FOLD_DEFER = None
@@ -851,7 +863,8 @@ class GraphedFineTunerStep(FineTunerStep):
         from .packed_train import PackedAdamW
         self.optimizer = PackedAdamW(self.trainer, lr=self.opt_kw["lr"], betas=self.opt_kw["betas"], eps=self.opt_kw["eps"],
                                      weight_decay=self.opt_kw["weight_decay"])
-        self._cap = dict(st=st, graph=graph, g_teacher=g_teacher, full_pred=full_pred, teacher_acts=teacher_acts,
+        self._cap = dict(st=st, graph=graph, g_bwd=g_bwd, g_teacher=g_teacher, full_pred=full_pred, teacher_acts=teacher_acts,
+                         pred=pred, student_acts=student_acts, side=torch.cuda.Stream(),
                          tail_stream=torch.cuda.Stream(), ev_bwd=torch.cuda.Event(), ev_tail=None, launch_log=launch_log, **out)
         self.trainer.sync = self.finish          # (export_ / state_dict read the parameters: after the pending optimizer tail)
         if self._dp_graphed:
@@ -869,7 +882,8 @@ class GraphedFineTunerStep(FineTunerStep):
         """nodes of the captured teacher + student forward / backward graph, when it was kept (graph_utils.KEEP_GRAPHS)"""
         if self._cap is None:
             return None
-        n = {"teacher": node_count(self._cap["g_teacher"]), "student_fwd_bwd": node_count(self._cap["graph"])}
+        n = {"teacher": node_count(self._cap["g_teacher"]), "student_fwd": node_count(self._cap["graph"]),
+             "student_bwd": node_count(self._cap["g_bwd"])}
         if self._wgrads is not None:
             n["batched_wgrad_launches"] = self._wgrads.launches()
         if self._folds is not None:
@@ -886,10 +900,15 @@ class GraphedFineTunerStep(FineTunerStep):
                 cap["st"][k].copy_(batch[k])
             cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
         main = torch.cuda.current_stream()
-        cap["g_teacher"].replay()                # reads no trainable state: runs next to the previous step's tail
+        side = cap["side"] if self.overlap_teacher else main
+        side.wait_stream(main)                   # (the batch copies above)
+        with torch.cuda.stream(side):
+            cap["g_teacher"].replay()            # reads no trainable state; own pool, own scratch domain: next to the student's forward
         if cap["ev_tail"] is not None:
             main.wait_event(cap["ev_tail"])      # parameters and operands of the previous step are in place
-        cap["graph"].replay()
+        cap["graph"].replay()                    # student forward
+        main.wait_stream(side)                   # teacher outputs ready
+        cap["g_bwd"].replay()                    # losses against the teacher + backward
         cap["ev_bwd"].record(main)
         tail = cap["tail_stream"] if self.overlap_tail else main
         with torch.cuda.stream(tail):

@@ -33,9 +33,12 @@ class ResourceLoss(nn.Module):
 
     def forward(self, resource_ratio):
         if self.loss_type == "log":
-            if resource_ratio > self.p:
-                return torch.log(resource_ratio / self.p)
-            return torch.log(self.p / resource_ratio)
+            if not torch.is_tensor(resource_ratio) or not resource_ratio.is_cuda:
+                if resource_ratio > self.p:
+                    return torch.log(resource_ratio / self.p)
+                return torch.log(self.p / resource_ratio)
+            # the same two branches without reading the comparison back on the host (one device -> host wait per step otherwise)
+            return torch.where(resource_ratio > self.p, torch.log(resource_ratio / self.p), torch.log(self.p / resource_ratio))
         if self.loss_type == "mae":
             return torch.abs(resource_ratio - self.p)
         return (resource_ratio - self.p) ** 2

@@ -107,6 +107,13 @@ class StructureVectorQuantizer(nn.Module):
             s += w
         return out
 
+    def _depth_order_on(self, device):
+        cache = self.__dict__.setdefault("_depth_order_cache", {})
+        t = cache.get(device)
+        if t is None:
+            t = cache[device] = torch.as_tensor(list(self.depth_order), dtype=torch.long).to(device)
+        return t
+
     def _seg_maps(self, device):
         """[n_width, n_seg] 0/1 membership of every width entry in its segment and the one-hot of each segment's first
         entry: the per-segment non-zero-width rule (estimation_utils.py:13-31) as two small matmuls instead of 70 slices."""
@@ -139,7 +146,7 @@ class StructureVectorQuantizer(nn.Module):
         d_sorted = importance_gumbel_softmax_sample(zd, temperature=self.temperature, offset=self.base, fixed_seed=fixed,
                                                     noise=nd)
         d = torch.zeros_like(d_sorted)
-        d[:, self.depth_order] = d_sorted
+        d[:, self._depth_order_on(d.device)] = d_sorted       # (a device index: a Python list here is a synchronous host->device copy per call)
         w = torch.sigmoid((zw + nwz + self.base) / self.temperature)
         if self.non_zero_width:
             member, first = self._seg_maps(z_q.device)

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--replays", type=int, default=100)
     ap.add_argument("--margin", type=float, default=0.0025)
     ap.add_argument("--budget-s", type=float, default=480.0)
+    ap.add_argument("--wide", type=int, default=0, help="also shortlist the N fastest (isolated, warm) of ALL (tile, split-K, order) "
+                    "combinations per shape and evaluate those in situ")
     ap.add_argument("--apply", action="store_true", help="also write the merged table over the package's own (for chained runs in one job)")
     args = ap.parse_args()
     t_start = time.time()
@@ -151,6 +153,47 @@ def main():
         return rc == 0
 
     committed = set(ops.TUNING)           # an expert run only ADDS entries: the headline / dense / train shapes keep theirs
+    def isolated_us(key, cd, reps=6):
+        """warm isolated time of one candidate on the recorded operands (None: cannot run); the recorded output is not written"""
+        q = clone_params(shapes[key]["params"])
+        q.tile, q.split_k, q.order = cd[0], cd[1], cd[2]
+        q.workspace = ws.data_ptr() if cd[1] > 1 else None
+        q.tile_counters = counters.data_ptr() if (cd[1] > 1 and (cd[3] or cd[0] >= ops.SK_TILE_FIRST)) else None
+        q.prefetch, q.prefetch_bytes = None, 0
+        if cd[1] > 1 and lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(q)) > (512 << 20):
+            return None
+        if q.B * q.Hout * q.Wout * max(q.ldy, q.N) * 4 > (512 << 20):
+            return None
+        q.y = ws.data_ptr() + (512 << 20)
+        q.residual = q.depth_in = None
+        s = torch.cuda.current_stream().cuda_stream
+        if lib.aptp_conv_gemm(ctypes.byref(q), s) != 0:
+            torch.cuda.synchronize()
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            lib.aptp_conv_gemm(ctypes.byref(q), s)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    def wide_shortlist(key, nK, n):
+        scored = []
+        for tile in range(1, ops.SK_TILE_FIRST):
+            for sk in (1, 2, 3, 4, 6, 8):
+                if sk > 1 and nK // sk < 3:
+                    continue
+                for o in (1, 3):
+                    us = isolated_us(key, (tile, sk, o, 1 if sk > 1 else 0))
+                    if us is None:
+                        break
+                    scored.append((us, (tile, sk, o, 1 if sk > 1 else 0)))
+                    if sk > 1:
+                        scored.append((us, (tile, sk, o, 0)))          # (the two-launch form: same GEMM time, decided in situ)
+        scored.sort(key=lambda t: t[0])
+        return [cd for _, cd in scored[:n]]
+
     base = max(measure(args.replays), measure(args.replays))
     out(f"baseline {base:.2f} steps/s, {len(shapes)} distinct shapes, visiting {len(order)}")
     changed = {}
@@ -177,8 +220,10 @@ def main():
                 cands.add((inc[0], sk, inc[2], 1 if sk > 1 else 0))
         for o in (2, 3):
             cands.add((inc[0], inc[1], o, inc[3]))
+        if args.wide:
+            cands.update(wide_shortlist(key, nK, args.wide))
         cands.discard(inc)
-        cands = [cd for cd in cands if not (cd[1] > 1 and nK // cd[1] < 3)][:28]
+        cands = [cd for cd in cands if not (cd[1] > 1 and nK // cd[1] < 3)][:28 + args.wide]
         best, best_v = inc, base
         saved = ops.TUNING.get(key)
         for cd in sorted(cands):

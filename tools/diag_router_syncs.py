@@ -14,6 +14,31 @@ from diffusion_pruning_amd.train_step import GraphedPrunerStep, synthetic_batch 
 from diffusion_pruning_amd.unet import UNet2DConditionModelGated  # noqa: E402
 
 dev = torch.device("cuda:0")
+if "--finetune" in sys.argv:
+    # the graphed expert fine-tune step instead
+    from bench import expert_mask  # noqa: E402
+    from diffusion_pruning_amd.train_step import GraphedFineTunerStep  # noqa: E402
+    from diffusion_pruning_amd.unet import UNet2DConditionModelPruned  # noqa: E402
+    teacher = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
+    teacher.freeze()
+    student = UNet2DConditionModelPruned().init_synthetic(seed=0).to(dev)
+    student.prune(expert_mask(student.get_structure(), 3, dev))
+    ft = GraphedFineTunerStep(student, teacher, lr=1e-5)
+    b = synthetic_batch(4, 64, dev, seed=1234)
+    ft.capture(b, offload_masters=True)
+    for _ in range(3):
+        ft.train_step(None, b)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("warn")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ft.train_step(None, b)
+    torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    print(f"fine-tune step: {len(w)} synchronising calls")
+    for x in w:
+        print(f"  {x.filename}:{x.lineno}  {str(x.message)[:100]}")
+    sys.exit(0)
 unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
 unet.freeze()
 st = unet.get_structure()

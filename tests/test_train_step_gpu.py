@@ -285,3 +285,34 @@ def test_teacher_graph_next_to_student_forward_is_race_free(cuda):
     for r in runs:
         for a, b in zip(r, ref):
             assert torch.equal(a, b)
+
+
+def test_router_has_no_host_synchronisation_and_the_same_values(cuda):
+    """The two places of the router that used to wait for the device every step (a Python-list index in the depth permutation of
+    gumbel_sigmoid_trick: a synchronous host->device copy; `if ratio > p` in ResourceLoss) are device-side now and give the
+    values and gradients of the host-side forms."""
+    from diffusion_pruning_amd.losses import ResourceLoss
+    rl = ResourceLoss(p=0.9)
+    for r0 in (0.97, 0.55, 0.9):
+        r_dev = torch.tensor(r0, device=cuda, requires_grad=True)
+        r_cpu = torch.tensor(r0, requires_grad=True)
+        a, b = rl(r_dev), rl(r_cpu)                       # device: torch.where of the two branches; host: the reference's if / else
+        a.backward(); b.backward()
+        assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 and abs(float(r_dev.grad) - float(r_cpu.grad)) <= 1e-5, r0
+    cfg, unet, params, hn, qz = build(cuda)
+    qz.to(cuda).train()
+    z = torch.randn(4, qz.vq_embed_dim, generator=torch.Generator().manual_seed(3)).to(cuda)
+    qz.gumbel_sigmoid_trick(z)                            # (first call: index / gather tables are uploaded once)
+    torch.manual_seed(77)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = qz.gumbel_sigmoid_trick(z)                  # would raise on any implicit device -> host wait
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    # the permutation itself: depth entries land where the list index put them
+    nw = sum(qz.width_list)
+    torch.manual_seed(77)
+    ref = qz.cpu().gumbel_sigmoid_trick(z.cpu())          # host path: same host-RNG stream, list semantics of index_put
+    qz.to(cuda)
+    assert torch.allclose(out[:, nw:].cpu(), ref[:, nw:], atol=2e-6) and torch.allclose(out.cpu(), ref, atol=2e-6)

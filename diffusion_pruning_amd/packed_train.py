@@ -11,7 +11,7 @@ architecture code -- and the bf16 operand the kernels read is its shadow:
     strided copy per data-gradient operand (the 180-degree-rotated transpose), instead of re-packing every weight from a
     diffusers-layout master (gather + permute + cast + pad: ~10 launches per weight, ~7,000 per step);
   * dead channels / heads / FF chunks / dropped blocks carry no optimizer state at all;
-  * nothing in the step depends on the host, so forward + backward + optimizer + refresh replay from one HIP graph
+  * nothing in the step depends on the host, so forward + backward replay from HIP graphs and the optimizer + refresh follow as three launches
     (train_step.GraphedFineTunerStep).
 
 Biases and norm affine parameters are compact fp32 tensors that the kernels read directly (no shadow).  The diffusers-named

@@ -701,10 +701,12 @@ class FineTunerStep:
 
 class GraphedFineTunerStep(FineTunerStep):
     """Expert fine-tuning with the trainable state in the kernels' layout (packed_train.PackedTrainer): dense teacher forward,
-    pruned student forward, the three loss terms (trainer.py:1730-1763) and the backward incl. weight gradients replayed from
-    ONE HIP graph, then AdamW (trainer.py:1529-1540) + the refresh of the bf16 operands as three launches
-    (packed_train.PackedAdamW).  The ~10^4 launches of the eager step (which is host-bound) cost their device time only.
-    Same numbers as FineTunerStep on packed masters with torch.optim.AdamW (tests/test_finetune_gpu.py)."""
+    pruned student forward, the three loss terms (trainer.py:1730-1763) and the backward replayed from THREE HIP graphs --
+    teacher (side stream, own pool) next to the student's forward, then losses + backward -- followed by the batched weight
+    gradients, the deferred folds, AdamW (trainer.py:1529-1540) and the refresh of the bf16 operands as a handful of launches
+    (ops.WgradBatch, ops.FoldBatch, packed_train.PackedAdamW).  The ~10^4 launches of the eager step (which is host-bound)
+    cost their device time only.  Same numbers as FineTunerStep on packed masters with the same optimizer, bit for bit
+    (tests/test_finetune_gpu.py)."""
 
     def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None,
                  lr: float = 1e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
@@ -752,8 +754,8 @@ class GraphedFineTunerStep(FineTunerStep):
         return (torch.stack([snr, cfg.snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0] / snr).float()
 
     def capture(self, batch: dict, warmup_iters: int = 2, offload_masters: bool = False):
-        """Build the packed trainable state, ONE HIP graph of teacher forward + student forward + losses + backward for this
-        batch geometry, and the one-launch AdamW over the gradients that graph leaves behind."""
+        """Build the packed trainable state, the three HIP graphs (teacher forward | student forward | losses + backward) for this
+        batch geometry, and the one-launch AdamW over the gradients the backward graph and the batched launches leave behind."""
         dev = batch["noisy_latents"].device
         st = {k: batch[k].clone() for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target")}
         if self.schedule.alphas_cumprod.device != dev:

@@ -72,6 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=("infer", "train", "finetune"), default="infer")
     ap.add_argument("--expert-offset", type=int, default=None, help="(finetune) rank r trains expert (r + offset) %% 8; default 3 at N = 1, else 0")
+    ap.add_argument("--data-parallel", action="store_true", help="(finetune) all ranks train ONE expert (expert --expert-offset), gradients "
+                    "averaged by the bucketed reducer")
     ap.add_argument("--no-extra-configs", action="store_true", help="(infer) skip the train / finetune measurements that follow the headline")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="(infer) length of the sustained-replay leg; 0 = off")
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
@@ -499,7 +501,10 @@ def run_finetune(R: Rank, steps=None, warmup=None, extras: bool = True):
     torch, args, dev = R.torch, R.args, R.dev
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    expert = (R.rank + args.expert_offset) % 8
+    # --data-parallel: ALL ranks train the same expert; the packed gradients the replayed graph leaves behind are
+    # averaged in buckets (reduce-scatter + all-gather) between the backward and the one-launch AdamW
+    dp = bool(args.data_parallel) and not R.cpu
+    expert = args.expert_offset % 8 if dp else (R.rank + args.expert_offset) % 8
     if R.cpu:
         step, batch, n_train, keep = _dryrun_install().install_finetune(expert, args.batch)
         nodes = fam = None
@@ -516,7 +521,7 @@ def run_finetune(R: Rank, steps=None, warmup=None, extras: bool = True):
         student.to(dev)
         student.prune(expert_mask(st, expert, dev))
         batch = synthetic_batch(args.batch, args.latent, dev, seed=1234 + R.rank)
-        step = GraphedFineTunerStep(student, teacher, lr=1e-5)
+        step = GraphedFineTunerStep(student, teacher, lr=1e-5, data_parallel=dp and R.dist)
         graph_utils.KEEP_GRAPHS = True
         ops.LAUNCH_LOG = [] if (extras and R.rank == 0) else None
         try:
@@ -551,19 +556,24 @@ def run_finetune(R: Rank, steps=None, warmup=None, extras: bool = True):
     if R.rank != 0:
         return None
     ms_per_step = elapsed / steps * 1e3
-    value = R.world * steps / elapsed
+    value = (1 if dp else R.world) * steps / elapsed             # data-parallel: ONE optimizer step per iteration for the whole job
     return {
         "metric": "expert-finetune-steps/s (APTP FineTuner.step: dense teacher fwd + pruned student fwd/bwd incl. weight gradients + "
-                  "AdamW, SD-2.1, 64x64 latents, bs=4 per GPU; one expert per GPU, summed over ranks)",
+                  "AdamW, SD-2.1, 64x64 latents, bs=4 per GPU; " + ("one expert on all GPUs, data-parallel)" if dp else
+                                                                   "one expert per GPU, summed over ranks)"),
         "value": round(value, 3), "unit": "steps/s", "n_gpus": R.n_seen, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[4]: expert fine-tune, 8 seeded architecture codes (keep 0.40-0.75, 0-4 depth gates "
-                               f"off), rank r trains expert (r + {args.expert_offset}) % 8, bs={args.batch}/GPU, whole step replayed from "
-                               "a HIP graph + one-launch AdamW",
+                               f"off), " + (f"all ranks train expert {expert}" if dp else f"rank r trains expert (r + {args.expert_offset}) % 8")
+                               + f", bs={args.batch}/GPU, step replayed from HIP graphs (teacher | student forward | loss + backward) "
+                               "+ batched weight gradients + one-launch AdamW",
                    "global_batch": args.batch * R.world,
-                   "parallelism": f"experts x{R.world}: one expert per GPU, no collective on the data path (finetune.py:27-28)"},
-        "per_gpu_steps_per_s": round(value / R.world, 3), "experts": per_rank, "graph_nodes_per_step": nodes,
+                   "parallelism": (f"dp{R.world}: one expert, packed gradients averaged in 64 MiB buckets (reduce-scatter + all-gather) "
+                                   "between the replayed backward and AdamW" if dp else
+                                   f"experts x{R.world}: one expert per GPU, no collective on the data path (finetune.py:27-28)")},
+        "samples_per_s": round(args.batch * R.world * steps / elapsed, 2),
+        "per_gpu_steps_per_s": round(value / (1 if dp else R.world), 3), "experts": per_rank, "graph_nodes_per_step": nodes,
         "launches_per_step": None if not nodes or None in nodes.values() else sum(nodes.values()) + 3,
         "family_roofline": fam, "max_mem_GiB": mem, "loss": loss,
     }

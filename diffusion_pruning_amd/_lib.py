@@ -169,7 +169,7 @@ class AdamWItem(Structure):
 class AdamWParams(Structure):
     _fields_ = [("items_dev", c_void_p), ("starts_dev", c_void_p), ("n_items", c_int32), ("total_blocks", c_int32),
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
-                ("step_dev", c_void_p)]
+                ("step_dev", c_void_p), ("gate_dev", c_void_p), ("grad_scale", c_float)]
 
 
 class MseParams(Structure):

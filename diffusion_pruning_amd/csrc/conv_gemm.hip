@@ -302,7 +302,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
   __bf16* Bs = smem + STAGES * BM * BK;
 #ifdef APTP_STAMPS
   const unsigned long long st_entry = __builtin_readcyclecounter();
-  unsigned long long st_phase[4] = {0, 0, 0, 0};
+  unsigned long long st_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -317,9 +317,11 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
   const int kt_begin = p.fd_sk.div(p.nK * kz);            // (nK * split_k < 2^31: checked on the host)
   const int kt_end = p.fd_sk.div(p.nK * (kz + 1));
   __shared__ unsigned pf_scratch[64];
+  APTP_PHASE(4);          // tile decoded (the first kernel-argument batches have arrived)
   prefetch_next(p, tid, NT, pf_scratch);
   LnRaw<MF> ln_raw;
   ln_rows_issue<MF, WTM>(p, m0, wm, lane, ln_raw);
+  APTP_PHASE(5);          // next-launch prefetch + LayerNorm statistics requested
 
   const int rowbase = tid >> 3;
   const int schunk = (tid & 7) ^ ((rowbase >> 1) & 7);      // source chunk that lands in this lane's LDS slot
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
     b_ptr[i] = reinterpret_cast<const char*>(p.w) + ((int64_t)n * p.Ktot + (int64_t)kt_begin * BK + schunk * 8) * 2;
   }
   set_tap(l_cc);
+  APTP_PHASE(6);          // operand addresses ready
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -578,6 +581,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
     if (n > 0) {
       const int pre = n < D ? n : D;
       for (int t = 0; t < pre; ++t) issue_tile(t);
+      APTP_PHASE(0);
       ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
       if (pre == D && D > 2) {   // tiles 0 and 1 landed, D-2 tiles still in flight
         if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 2)) : "memory");
@@ -587,6 +591,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      APTP_PHASE(1);
       int cur = 0, nxt = D;
       for (int kt = 0; kt < n; kt += 2) {
         const int ni = n - (kt + D);          // tiles left to request: two per iteration while >= 2
@@ -612,8 +617,10 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
   if constexpr (STAGES == 2) {
     if (kt_begin < kt_end) {
       issue_tile(0);
+      APTP_PHASE(0);
       ln_rows_finish<MF>(p, lane, ln_raw, ln_mean, ln_rstd);
       __syncthreads();                       // (the compiler drains vmcnt(0) for the LDS-DMA before the barrier)
+      APTP_PHASE(1);
       int buf = 0;
       for (int kt = kt_begin; kt < kt_end; ++kt) {
         APTP_STAMP(0);
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
   APTP_PHASE(3);
   if (lane == 0 && kz == 0) {
     const int slot = (blockIdx.x * NW + wave) & 4095;
-    for (int i = 0; i < 4; ++i) g_phase[slot * 4 + i] = st_phase[i];
+    for (int i = 0; i < 8; ++i) g_phase[slot * 8 + i] = st_phase[i];
   }
 #endif
 }

@@ -9,7 +9,7 @@
 __device__ unsigned long long g_stamps[4096 * 4];
 // launch timeline of a wave (cycles since its first instruction): [0] prologue DMA issued, [1] first tile landed (first
 // barrier passed), [2] K loop done, [3] epilogue done and its stores drained
-__device__ unsigned long long g_phase[4096 * 4];
+__device__ unsigned long long g_phase[4096 * 8];   // + [4] tile decoded, [5] prefetch / statistics requested, [6] addresses ready
 #define APTP_PHASE(i) do { st_phase[i] = __builtin_readcyclecounter() - st_entry; } while (0)
 // epilogue timeline (absolute cycles): [0] entry, [1] stages free (barrier passed), [2] first fragment's per-column half in LDS,
 // [4] all stores issued, [5] stores drained
@@ -545,6 +545,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
         }
       }
     }
+    if (i == 0) APTP_EPI(3);
   }
   APTP_EPI(4);
   if constexpr (!GEGLU && WL >= 32) {

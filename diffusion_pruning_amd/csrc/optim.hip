@@ -18,6 +18,8 @@ struct AdamK {
   const AptpAdamWItem* items; const int32_t* starts; int n_items;
   float lr, beta1, beta2, eps, wd;
   const float* step;                            // device scalar: number of steps taken BEFORE this one
+  const float* gate;                            // optional device scalar: the step is applied only when it is finite
+  float gscale;                                 // gradients are multiplied by this first (1 / world size of a summed exchange)
 };
 
 __global__ __launch_bounds__(256) void adamw_many_kernel(const AdamK k) {
@@ -26,6 +28,13 @@ __global__ __launch_bounds__(256) void adamw_many_kernel(const AdamK k) {
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (k.starts[mid] <= b) lo = mid; else hi = mid;
+  }
+  // NaN guard of a replayed graph (reference: pdm/training/trainer.py:921-929 skips the batch whose backward produced
+  // NaNs): a non-finite loss leaves parameters, moments and operands untouched; the caller advances the step count by
+  // the same predicate.  Uniform over the grid: one scalar load.
+  if (k.gate) {
+    const float gv = k.gate[0];
+    if (!(fabsf(gv) <= 3.0e38f)) return;
   }
   const AptpAdamWItem it = k.items[lo];
   const float t = k.step[0] + 1.0f;
@@ -41,7 +50,8 @@ __global__ __launch_bounds__(256) void adamw_many_kernel(const AdamK k) {
       const float4 g = *reinterpret_cast<const float4*>(it.g + e);
       float4 m = *reinterpret_cast<const float4*>(it.m + e);
       float4 v = *reinterpret_cast<const float4*>(it.v + e);
-      float* pp = &p.x; const float* gg = &g.x; float* mm = &m.x; float* vv = &v.x;
+      float* pp = &p.x; const float* g0 = &g.x; float* mm = &m.x; float* vv = &v.x;
+      const float gg[4] = {g0[0] * k.gscale, g0[1] * k.gscale, g0[2] * k.gscale, g0[3] * k.gscale};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         pp[j] *= decay;
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(256) void adamw_many_kernel(const AdamK k) {
     } else {
       for (int64_t x = e; x < it.n && x < e + 4; ++x) {
         float p = it.p[x] * decay;
-        const float g = it.g[x];
+        const float g = it.g[x] * k.gscale;
         const float m = k.beta1 * it.m[x] + (1.0f - k.beta1) * g;
         const float v = k.beta2 * it.v[x] + (1.0f - k.beta2) * g * g;
         p -= step_size * m / (sqrtf(v) / bc2_sqrt + k.eps);
@@ -77,7 +87,9 @@ extern "C" int aptp_adamw_blocks(int64_t n) { return n <= 0 ? 0 : (int)((n + ELE
 extern "C" int aptp_adamw_many(const AptpAdamWParams* p, aptp_stream_t stream) {
   APTP_CHECK(p && p->items_dev && p->starts_dev && p->step_dev && p->n_items >= 1 && p->total_blocks >= 1, "adamw_many: bad arguments");
   APTP_CHECK(p->lr >= 0.f && p->beta1 >= 0.f && p->beta1 < 1.f && p->beta2 >= 0.f && p->beta2 < 1.f && p->eps > 0.f, "adamw_many: hyper-parameters");
-  AdamK k{p->items_dev, p->starts_dev, p->n_items, p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->step_dev};
+  APTP_CHECK(p->grad_scale >= 0.f, "adamw_many: grad_scale");
+  AdamK k{p->items_dev, p->starts_dev, p->n_items, p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->step_dev,
+          p->gate_dev, p->grad_scale == 0.f ? 1.0f : p->grad_scale};
   hipLaunchKernelGGL(adamw_many_kernel, dim3((unsigned)p->total_blocks), dim3(256), 0, (hipStream_t)stream, k);
   APTP_LAUNCH_CHECK();
   return APTP_OK;

@@ -471,6 +471,11 @@ typedef struct {
   const AptpAdamWItem* items_dev; const int32_t* starts_dev; int32_t n_items, total_blocks;
   float lr, beta1, beta2, eps, weight_decay;
   const float* step_dev;
+  const float* gate_dev;  /* optional fp32 device scalar (e.g. the step's total loss): the launch is a no-op unless it is finite --
+                           * the batch-skip of pdm/training/trainer.py:921-929 for a replayed graph; the caller advances step_dev
+                           * by the same predicate */
+  float grad_scale;       /* gradients are multiplied by this before use (0 = 1): 1 / world size folds the mean of a summed
+                           * data-parallel exchange (DDP inside accelerator.backward, trainer.py:1616) into the optimizer pass */
 } AptpAdamWParams;
 int aptp_adamw_blocks(int64_t n);
 int aptp_adamw_many(const AptpAdamWParams* p, aptp_stream_t stream);

@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=("infer", "train", "finetune"), default="infer")
     ap.add_argument("--expert-offset", type=int, default=None, help="(finetune) rank r trains expert (r + offset) %% 8; default 3 at N = 1, else 0")
     ap.add_argument("--data-parallel", action="store_true", help="(finetune) all ranks train ONE expert (expert --expert-offset), gradients "
-                    "averaged by the bucketed reducer")
+                    "summed in place over the gradient arena (train_step.ArenaGradReducer), mean folded into AdamW")
     ap.add_argument("--no-extra-configs", action="store_true", help="(infer) skip the train / finetune measurements that follow the headline")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="(infer) length of the sustained-replay leg; 0 = off")
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
@@ -569,13 +569,18 @@ def run_finetune(R: Rank, steps=None, warmup=None, extras: bool = True):
                                + f", bs={args.batch}/GPU, step replayed from HIP graphs (teacher | student forward | loss + backward) "
                                "+ batched weight gradients + one-launch AdamW",
                    "global_batch": args.batch * R.world,
-                   "parallelism": (f"dp{R.world}: one expert, packed gradients averaged in 64 MiB buckets (reduce-scatter + all-gather) "
-                                   "between the replayed backward and AdamW" if dp else
+                   "parallelism": (f"dp{R.world}: one expert; the gradient arena is summed over the ranks IN PLACE in 256 MiB buckets "
+                                   "(reduce-scatter + all-gather on a communication stream), AdamW follows bucket by bucket with "
+                                   "grad_scale = 1/world" if dp else
                                    f"experts x{R.world}: one expert per GPU, no collective on the data path (finetune.py:27-28)")},
         "samples_per_s": round(args.batch * R.world * steps / elapsed, 2),
         "per_gpu_steps_per_s": round(value / (1 if dp else R.world), 3), "experts": per_rank, "graph_nodes_per_step": nodes,
         "launches_per_step": None if not nodes or None in nodes.values() else sum(nodes.values()) + 3,
         "family_roofline": fam, "max_mem_GiB": mem, "loss": loss,
+        "gradient_exchange": None if (R.cpu or getattr(step, "reducer", None) is None) else {
+            "buckets": len(step.reducer.buckets), "mode": step.reducer.mode, "arena_MiB": round(step.reducer.arena.numel() * 4 / 2 ** 20, 1),
+            "collectives_per_step": step.reducer.stats["collectives"] / max(1, step.reducer.stats["steps"]),
+            "per_tensor_ops_per_step": step.reducer.stats["tensor_ops"], "issued_on_backend": bool(step.reducer.active)},
     }
 
 

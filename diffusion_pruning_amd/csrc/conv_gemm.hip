@@ -1394,6 +1394,14 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     k.fd_tm = make_fastdiv(tiles_m); k.fd_tn = make_fastdiv(tiles_n); k.fd_sk = make_fastdiv(k.split_k);
     k.fd_perm = make_fastdiv(tiles_n * k.split_k); k.fd_tmn = make_fastdiv(tiles_m * tiles_n);
   }
+  // plain linear layers take the lean kernel of the same tile shape (lin_gemm.hip); APTP_LIN=0 keeps them here (A/B timing, tests)
+  static const bool lin_on = !(getenv("APTP_LIN") && getenv("APTP_LIN")[0] == '0');
+  if (lin_on && p->epilogue != 2 && aptp_lin_eligible(k, t)) {
+    const int rc2 = aptp_launch_lin(k, t, s);
+    if (rc2 != APTP_OK) return rc2;
+    APTP_LAUNCH_CHECK();
+    return APTP_OK;
+  }
   switch (t) {
     case APTP_TILE_128x128: launch_tile<128, 128>(k, s); break;
     case APTP_TILE_128x160: launch_tile<128, 160>(k, s); break;

@@ -64,6 +64,7 @@ struct KParams {
   int64_t ws_ld;            // workspace row stride (floats)
   int order;                // workgroup -> tile order (decode_block): 0 legacy, 1 weight-major, 2 activation-major
   const char* pf_ptr; int64_t pf_bytes;   // operand of the NEXT launch to pull towards the Infinity Cache (prefetch_next)
+  int pf_lines, pf_per;                   // lin_gemm_kernel: 64-byte lines of pf_ptr, lines per workgroup slice (host-computed)
   int* counters;            // in-kernel split-K: one arrival counter per output tile (zero on entry, left zero)
   float* cstat_out; int cstat_ld;   // per-(row block, channel) (sum, sumsq) of the stored outputs: GroupNorm statistics
   int epi16;                // 1: bf16 output (and residual / depth_in) rows are 16-byte aligned -> coalesced epilogue
@@ -710,5 +711,8 @@ inline FastDiv make_fastdiv(int d) {
 // conv_gemm_sk.hip: persistent stream-K macro-tile kernels (APTP_TILE_SK_*)
 int aptp_sk_cus();                                              // CUs of the current device = workgroups of a launch
 int aptp_launch_sk(const KParams& k, int tile, hipStream_t s);
+// lin_gemm.hip: lean kernels for plain linear layers (1x1, stride 1, one K-slice, coalesced bf16 epilogue)
+bool aptp_lin_eligible(const KParams& k, int tile);
+int aptp_launch_lin(const KParams& k, int tile, hipStream_t s);
 
 }  // namespace aptp_cg

@@ -192,12 +192,34 @@ class PackedTrainer:
         return ps
 
     @torch.no_grad()
-    def ensure_grad_buffers(self):
+    def ensure_grad_buffers(self, arena: bool = False, world: int = 1):
         """persistent, zero-initialised .grad for every packed tensor (direct-gradient mode, ops.GRAD_DIRECT): the kernels write
-        the live region of each buffer every step and never touch the pad columns"""
-        for p in self.parameters():
-            if p.grad is None or p.grad.shape != p.shape:
-                p.grad = torch.zeros_like(p)
+        the live region of each buffer every step and never touch the pad columns.
+        arena=True: all of them are views into ONE contiguous fp32 buffer (``self.grad_arena``; ``self.grad_offsets`` = element
+        offset per parameter, in self.parameters() order), laid out in REVERSE registration order -- the order a backward
+        produces gradients in -- with 256-byte aligned views; slot 0 (the first 64 elements) is reserved for the step's loss
+        (train_step.ArenaGradReducer: the data-parallel exchange then runs in place on contiguous ranges, and its sum of the losses
+        is the ranks' common NaN verdict); the total is padded to a multiple of 64 * world elements (equal shards)."""
+        ps = self.parameters()
+        if not arena:
+            for p in ps:
+                if p.grad is None or p.grad.shape != p.shape:
+                    p.grad = torch.zeros_like(p)
+            return self
+        if getattr(self, "grad_arena", None) is not None and len(self.grad_offsets) == len(ps) and self._arena_world == world:
+            return self
+        A = 64
+        offs, off = [0] * len(ps), A                    # [0, 64): loss slot
+        for i in reversed(range(len(ps))):
+            offs[i] = off
+            off += (ps[i].numel() + A - 1) // A * A
+        q = A * max(1, world)
+        total = (off + q - 1) // q * q
+        buf = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
+        for p, o in zip(ps, offs):
+            assert p.dtype == torch.float32 and p.is_contiguous()
+            p.grad = buf[o:o + p.numel()].view_as(p)
+        self.grad_arena, self.grad_offsets, self._arena_world = buf, offs, world
         return self
 
     def named_parameters(self):
@@ -271,10 +293,15 @@ class PackedAdamW:
     (csrc/optim.hip).  The gradient tensors must exist and stay where they are (``.grad`` of every parameter as left by the
     captured backward of GraphedFineTunerStep: the graph re-writes the same addresses at every replay)."""
 
-    def __init__(self, trainer: PackedTrainer, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+    def __init__(self, trainer: PackedTrainer, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 group_of=None):
+        """group_of: optional map parameter -> group index (e.g. the gradient bucket that completes it, ArenaGradReducer.bucket_of):
+        the table is built per group and ``step_group(i)`` applies one group per launch, so the optimizer can follow a
+        bucketed gradient exchange bucket by bucket; ``step()`` applies all groups."""
         import ctypes
         from . import _lib
         self.trainer, self.lr, self.betas, self.eps, self.weight_decay = trainer, lr, betas, eps, weight_decay
+        self.group_of = group_of
         entries = []                                   # (parameter, bf16 shadow or None)
         for e in trainer.gemms.values():
             entries.append((e.P, e.pw.w))
@@ -317,21 +344,63 @@ class PackedAdamW:
         self.items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
         self.starts = torch.tensor(starts, dtype=torch.int32).to(dev)
         self.n, self.total = len(self.entries), starts[-1]
+        # per-group tables (bucketed data-parallel exchange): the same descriptors, regrouped, with block prefixes of their own
+        self.groups = None
+        if self.group_of is not None:
+            import ctypes
+            isz = ctypes.sizeof(_lib.AdamWItem)
+            raw = bytes(items)
+            by = {}
+            for i, p in enumerate(self.params):
+                by.setdefault(int(self.group_of(p)), []).append(i)
+            self.groups = {}
+            for gi, idx in sorted(by.items()):
+                st = [0]
+                for i in idx:
+                    st.append(st[-1] + (starts[i + 1] - starts[i]))
+                blob = b"".join(raw[i * isz:(i + 1) * isz] for i in idx)
+                self.groups[gi] = (torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev),
+                                   torch.tensor(st, dtype=torch.int32).to(dev), len(idx), st[-1])
         return self
 
-    @torch.no_grad()
-    def step(self):
+    def _launch(self, items, starts, n, total, gate, grad_scale):
         import ctypes
         from . import _lib
-        for p, g in zip(self.params, self.grads):
-            assert p.grad is g, "PackedAdamW: a gradient tensor was replaced (its address is part of the kernel's table)"
         lib = _lib.load()
         q = _lib.AdamWParams()
-        q.items_dev, q.starts_dev, q.n_items, q.total_blocks = self.items.data_ptr(), self.starts.data_ptr(), self.n, self.total
+        q.items_dev, q.starts_dev, q.n_items, q.total_blocks = items.data_ptr(), starts.data_ptr(), n, total
         q.lr, q.beta1, q.beta2, q.eps, q.weight_decay = self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay
         q.step_dev = self.step_t.data_ptr()
+        q.gate_dev = None if gate is None else gate.data_ptr()
+        q.grad_scale = float(grad_scale)
         _lib.check(lib.aptp_adamw_many(ctypes.byref(q), ops._stream()), "aptp_adamw_many")
-        self.step_t += 1.0
+
+    def _check_grads(self):
+        for p, g in zip(self.params, self.grads):
+            assert p.grad is g, "PackedAdamW: a gradient tensor was replaced (its address is part of the kernel's table)"
+
+    @torch.no_grad()
+    def step(self, gate: torch.Tensor = None, grad_scale: float = 1.0):
+        """one AdamW step over every tensor (one launch).  gate: optional fp32 device scalar (the step's loss): the whole step
+        -- parameters, moments, operands and the step count -- is skipped unless it is finite (reference: the batch skip of
+        pdm/training/trainer.py:921-929); grad_scale multiplies the gradients first (1 / world after a summed exchange)."""
+        self._check_grads()
+        self._launch(self.items, self.starts, self.n, self.total, gate, grad_scale)
+        self.finish_step(gate)
+
+    @torch.no_grad()
+    def step_group(self, gi: int, gate: torch.Tensor = None, grad_scale: float = 1.0):
+        """the tensors of group gi only (no step-count update: call finish_step() after the last group)"""
+        if gi in self.groups:
+            items, starts, n, total = self.groups[gi]
+            self._launch(items, starts, n, total, gate, grad_scale)
+
+    @torch.no_grad()
+    def finish_step(self, gate: torch.Tensor = None):
+        if gate is None:
+            self.step_t += 1.0
+        else:
+            self.step_t += torch.isfinite(gate.reshape(())).to(torch.float32)
         self.trainer.refresh_(shadows_done=True)
 
     def state_dict(self):

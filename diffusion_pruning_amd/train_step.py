@@ -218,6 +218,100 @@ class BucketedGradReducer:
         self.reset()
 
 
+class ArenaGradReducer:
+    """Data-parallel gradient exchange of the graphed expert fine-tune (DDP inside accelerator.backward,
+    pdm/training/trainer.py:1616) over ONE contiguous gradient arena (packed_train.PackedTrainer.ensure_grad_buffers(arena=True):
+    every packed parameter's .grad is a view into it).  MI355X-first:
+      * buckets are contiguous RANGES of the arena, so every collective runs in place on the memory the backward wrote and the
+        optimizer reads: no staging buffer, no copy, no per-parameter kernel (the round-3 reducer issued ~3 tiny launches per packed
+        tensor and step);
+      * mode "rs_ag": reduce_scatter_tensor + all_gather_into_tensor per bucket, both in place (the rank's shard is a slice of the
+        bucket) -- on the fully connected xGMI mesh each is ONE direct exchange between all pairs of GPUs over 7 links at once,
+        where a ring all-reduce is 2(n-1) dependent per-link steps; mode "all_reduce": one collective per bucket;
+      * the collectives are queued on a communication stream, bucket after bucket, and an event per bucket lets the consumer
+        (the one-launch-per-bucket AdamW) start on bucket i while bucket i+1 is still on the links: what is exposed is one bucket,
+        not the whole exchange;
+      * the SUM stays in the arena: the 1 / world of the mean is AptpAdamWParams.grad_scale, folded into the optimizer's pass;
+      * slot 0 of the arena carries the step's loss, so after the exchange it holds the sum over the ranks: one finite / non-finite
+        verdict shared by all ranks (AptpAdamWParams.gate_dev) without a collective of its own.
+    Issues its collectives whenever a process group is initialised -- also at world size 1 (bench.py under
+    APTP_BENCH_FORCE_DIST: RCCL then runs every call of the schedule on one GPU)."""
+
+    ALIGN = 64            # elements: bucket and shard boundaries are 256-byte aligned
+
+    def __init__(self, arena: torch.Tensor, bucket_bytes: int = 256 << 20, mode: str = "rs_ag", group=None):
+        assert mode in ("all_reduce", "rs_ag"), mode
+        assert arena.dim() == 1 and arena.is_contiguous() and arena.dtype == torch.float32
+        self.arena, self.mode, self.group = arena, mode, group
+        self.world, self.rank = _world(), _rank()
+        q = self.ALIGN * self.world
+        assert arena.numel() % q == 0, "the arena is padded to a multiple of ALIGN * world elements (PackedTrainer does it)"
+        per = max(q, (bucket_bytes // 4) // q * q)
+        self.bounds: List[tuple] = []
+        off = 0
+        while off < arena.numel():
+            end = min(arena.numel(), off + per)
+            self.bounds.append((off, end))
+            off = end
+        self.buckets = [arena[a:b] for a, b in self.bounds]
+        self.shards = [bk[(bk.numel() // self.world) * self.rank:(bk.numel() // self.world) * (self.rank + 1)] for bk in self.buckets]
+        self.stream = torch.cuda.Stream(device=arena.device) if arena.is_cuda else None
+        self.events = [torch.cuda.Event() for _ in self.buckets] if arena.is_cuda else None
+        self.stats = {"collectives": 0, "tensor_ops": 0, "steps": 0}
+
+    @property
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized()
+
+    def bucket_of(self, offset: int, numel: int) -> int:
+        """bucket that completes the arena range [offset, offset + numel): the one holding its LAST element"""
+        last = offset + numel - 1
+        for i, (a, b) in enumerate(self.bounds):
+            if a <= last < b:
+                return i
+        raise ValueError("range outside the arena")
+
+    def exchange(self, on_bucket=None):
+        """sum the arena over the ranks, bucket by bucket; on_bucket(i) is called once bucket i's sum is in place for the CURRENT
+        stream (device side: the current stream waits for the bucket's event; nothing blocks the host on the GPU)"""
+        self.stats["steps"] += 1
+        if not self.active:
+            for i in range(len(self.buckets)):
+                if on_bucket is not None:
+                    on_bucket(i)
+            return
+        cuda = self.stream is not None
+        if cuda:
+            main = torch.cuda.current_stream()
+            self.stream.wait_stream(main)              # the gradients are complete on the launching stream
+        ctx = torch.cuda.stream(self.stream) if cuda else _NullCtx()
+        with ctx:
+            for i, (bk, sh) in enumerate(zip(self.buckets, self.shards)):
+                with _span("grad bucket %d" % i):
+                    if self.mode == "rs_ag":
+                        dist.reduce_scatter_tensor(sh, bk, group=self.group)
+                        dist.all_gather_into_tensor(bk, sh, group=self.group)
+                        self.stats["collectives"] += 2
+                    else:
+                        dist.all_reduce(bk, group=self.group)
+                        self.stats["collectives"] += 1
+                if cuda:
+                    self.events[i].record(self.stream)
+        for i in range(len(self.buckets)):
+            if cuda:
+                torch.cuda.current_stream().wait_event(self.events[i])
+            if on_bucket is not None:
+                on_bucket(i)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def _mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """mean((a - b)^2) in fp32 with the gradient flowing into ``a`` only (b: target / teacher side).  On the GPU the HIP
     reduction (autograd.MseFn: no fp32 copies, fixed order, safe inside replayed graphs); host tensors (the CPU suite's
@@ -710,12 +804,15 @@ class GraphedFineTunerStep(FineTunerStep):
 
     def __init__(self, student, teacher, cfg: Optional[FinetuneLossConfig] = None, schedule: Optional[NoiseSchedule] = None,
                  lr: float = 1e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
-                 data_parallel: bool = False, bucket_bytes: int = 64 << 20, reduce_mode: str = "rs_ag"):
+                 data_parallel: bool = False, bucket_bytes: int = 256 << 20, reduce_mode: str = "rs_ag", nan_guard: bool = True):
         super().__init__(student, teacher, cfg, schedule)
-        # data_parallel (one expert on several GPUs): the replayed graph leaves this rank's gradients in the
-        # packed tensors' .grad; they are averaged over the ranks in buckets (no hooks: nothing of a replay runs on the
-        # host) between the replay and the one-launch AdamW
+        # data_parallel (one expert on several GPUs): the replayed graph and the batched weight-gradient launches
+        # leave this rank's gradients in ONE contiguous arena; ArenaGradReducer sums it over the ranks in place, bucket by bucket
+        # on a communication stream, and the optimizer follows bucket by bucket (the mean is its grad_scale)
         self._dp_graphed, self._bucket_bytes, self._reduce_mode = data_parallel, bucket_bytes, reduce_mode
+        # nan_guard: a step whose loss is not finite leaves parameters, moments and the step count untouched (device-side:
+        # AptpAdamWParams.gate_dev; reference: the batch skip of pdm/training/trainer.py:921-929)
+        self.nan_guard = nan_guard
         self.defer_folds, self.direct_grads, self._folds = True, True, None
         self.defer_wgrads, self._wgrads = True, None
         self.overlap_teacher = os.environ.get("APTP_FT_OVERLAP_TEACHER", "1") != "0"   # teacher graph on a side stream next to the student's forward
@@ -775,7 +872,7 @@ class GraphedFineTunerStep(FineTunerStep):
         # to reset between steps -- every parameter's live region is overwritten by each backward
         direct = self.direct_grads
         if direct:
-            self.trainer.ensure_grad_buffers()
+            self.trainer.ensure_grad_buffers(arena=self._dp_graphed, world=_world())
 
         def teacher_fwd():
             # own split-K counters / scratch: this graph replays NEXT TO the previous step's optimizer tail (ops.scratch_domain)
@@ -863,14 +960,18 @@ class GraphedFineTunerStep(FineTunerStep):
         # left in `.grad`, which every replay re-writes in place.  It runs right behind the graph, followed by the one-launch
         # refresh of the data-gradient operands: three launches, no host work worth capturing.
         from .packed_train import PackedAdamW
+        group_of = None
+        if self._dp_graphed:
+            assert direct, "the data-parallel graphed step exchanges the gradient arena of the direct-gradient mode"
+            self.reducer = ArenaGradReducer(self.trainer.grad_arena, self._bucket_bytes, mode=self._reduce_mode)
+            off = {id(p_): o for p_, o in zip(self.trainer.parameters(), self.trainer.grad_offsets)}
+            group_of = lambda p_: self.reducer.bucket_of(off[id(p_)], p_.numel())          # noqa: E731
         self.optimizer = PackedAdamW(self.trainer, lr=self.opt_kw["lr"], betas=self.opt_kw["betas"], eps=self.opt_kw["eps"],
-                                     weight_decay=self.opt_kw["weight_decay"])
+                                     weight_decay=self.opt_kw["weight_decay"], group_of=group_of)
         self._cap = dict(st=st, graph=graph, g_bwd=g_bwd, g_teacher=g_teacher, full_pred=full_pred, teacher_acts=teacher_acts,
                          pred=pred, student_acts=student_acts, side=torch.cuda.Stream(),
                          tail_stream=torch.cuda.Stream(), ev_bwd=torch.cuda.Event(), ev_tail=None, launch_log=launch_log, **out)
         self.trainer.sync = self.finish          # (export_ / state_dict read the parameters: after the pending optimizer tail)
-        if self._dp_graphed:
-            self.reducer = BucketedGradReducer(self.optimizer.params, self._bucket_bytes, mode=self._reduce_mode, hooks=False)
         return self
 
     def finish(self):
@@ -920,8 +1021,16 @@ class GraphedFineTunerStep(FineTunerStep):
             if self._folds is not None:
                 self._folds.run()                # every deferred slab / chunk fold of the backward: one launch
             if self._dp_graphed and self.reducer is not None:
-                self.reducer.exchange_all()      # mean over the ranks, written in place (the optimizer's table holds these addresses)
-            self.optimizer.step()
+                # sum over the ranks in place, bucket by bucket on the communication stream; AdamW follows bucket by bucket with
+                # grad_scale = 1 / world; arena slot 0 = sum of the ranks' losses = their common finite / non-finite verdict
+                arena = self.trainer.grad_arena
+                arena[0:1].copy_(cap["total"].reshape(1))
+                gate = arena[0:1] if self.nan_guard else None
+                scale = 1.0 / self.reducer.world
+                self.reducer.exchange(lambda i: self.optimizer.step_group(i, gate, scale))
+                self.optimizer.finish_step(gate)
+            else:
+                self.optimizer.step(cap["total"] if self.nan_guard else None)
             ev = cap["ev_tail"] or torch.cuda.Event()
             ev.record(tail)
             cap["ev_tail"] = ev

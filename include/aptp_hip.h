@@ -129,7 +129,8 @@ typedef struct {
   const void* prefetch;
   int64_t prefetch_bytes;
   int32_t epilogue;     /* 0 = auto (coalesced 16-byte stores through an LDS transpose when y / residual / depth_in rows are
-                         * 16-byte aligned), 1 = force the accumulator-layout epilogue (testing / tuning) */
+                         * 16-byte aligned), 1 = force the accumulator-layout epilogue (testing / tuning), 2 = keep a plain linear layer on the
+                         * general implicit-GEMM kernel instead of the lean one of csrc/lin_gemm.hip (testing: the two must agree) */
   /* optional, small maps (Hout*Wout <= 256), split_k > 1 without tile_counters: the reduce launch of the split also applies
    * the GroupNorm(+SiLU) that follows this convolution (ResnetBlock2D: conv1 + time_emb_proj -> norm2 -> SiLU,
    * blocks.py:331-359): one workgroup per (sample, group) sums the K-slices of its Hout*Wout x (gn_C / gn_groups) columns,

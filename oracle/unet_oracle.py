@@ -308,7 +308,7 @@ def hard(gate: torch.Tensor) -> torch.Tensor:
 def timestep_embedding(timesteps: torch.Tensor, dim: int, dtype) -> torch.Tensor:
     """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]."""
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half
     emb = timesteps.to(torch.float32)[:, None] * torch.exp(exponent)[None, :]
     emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
     emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)  # flip_sin_to_cos

@@ -263,3 +263,42 @@ def test_exchange_all_without_hooks_writes_means_in_place():
         for r in (0, 1):
             assert res[r][mode + "_inplace"]
             assert torch.allclose(res[r][mode], torch.full_like(res[r][mode], 1.5), atol=1e-6)
+
+
+def _arena_worker(rank, world):
+    """ArenaGradReducer over a flat fp32 'gradient arena': in-place bucketed exchange, both modes"""
+    from diffusion_pruning_amd.train_step import ArenaGradReducer
+    out = {}
+    n = 64 * world * 37                       # several buckets of 64 * world * 8 elements, a short last one
+    for mode in ("rs_ag", "all_reduce"):
+        g = torch.Generator().manual_seed(7 + rank)
+        arena = torch.randn(n, generator=g)
+        mine = arena.clone()
+        red = ArenaGradReducer(arena, bucket_bytes=4 * 64 * world * 8, mode=mode)
+        seen = []
+        ptr = arena.data_ptr()
+        red.exchange(lambda i: seen.append(i))
+        assert arena.data_ptr() == ptr and seen == list(range(len(red.buckets)))
+        out[mode] = arena.clone()
+        out[mode + "_mine"] = mine
+        out[mode + "_nb"] = len(red.buckets)
+        out[mode + "_coll"] = red.stats["collectives"]
+        out[mode + "_ops"] = red.stats["tensor_ops"]
+        # bucket_of: a range is complete with the bucket that holds its last element
+        assert red.bucket_of(0, 1) == 0 and red.bucket_of(0, n) == len(red.buckets) - 1
+        a, b = red.bounds[1]
+        assert red.bucket_of(a - 3, 3) == 0 and red.bucket_of(a - 3, 4) == 1
+    return out
+
+
+def test_arena_reducer_sums_in_place_with_two_collectives_per_bucket():
+    """train_step.ArenaGradReducer (the graphed fine-tune's data-parallel exchange, trainer.py:1616): the arena ends up holding the
+    SUM over the ranks, bit-equal on both ranks and equal to the directly computed sum; 2 collectives per bucket in rs_ag mode,
+    1 in all_reduce mode, no per-tensor operation, nothing re-allocated"""
+    res = _run(_arena_worker)
+    for mode, per in (("rs_ag", 2), ("all_reduce", 1)):
+        total = res[0][mode + "_mine"] + res[1][mode + "_mine"]
+        assert torch.equal(res[0][mode], res[1][mode])                      # replicas agree bit for bit
+        assert torch.equal(res[0][mode], total)                             # two-term fp32 sums: exact
+        assert res[0][mode + "_nb"] == 5
+        assert res[0][mode + "_coll"] == per * res[0][mode + "_nb"] and res[0][mode + "_ops"] == 0

@@ -302,3 +302,129 @@ def test_one_launch_adamw_matches_torch_adamw(cuda):
     other["names"] = ["x" + n for n in sd["names"]]
     with pytest.raises(AssertionError):
         opt3.load_state_dict(other)
+
+
+def test_adamw_gate_grad_scale_and_groups(cuda):
+    """AptpAdamWParams.gate_dev / grad_scale and the per-group tables of PackedAdamW: a non-finite gate leaves parameters,
+    moments, operands and the step count untouched (the batch skip of pdm/training/trainer.py:921-929 for a replayed graph);
+    grad_scale = 1 / w on w-times-summed gradients is the step on the mean; stepping group by group equals one launch."""
+    from types import SimpleNamespace
+    from diffusion_pruning_amd.packed_train import PackedAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 9, 72), (8, 1, 8), (1283,), (5,), (4096 * 3 + 7,)]
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=torch.Generator().manual_seed(11 + i)).to(cuda)) for i, s in enumerate(shapes)]
+        sh = [torch.zeros(s, dtype=torch.bfloat16, device=cuda) for s in shapes[:2]]
+        gemms = {0: SimpleNamespace(P=ps[0], Pb=ps[2], pw=SimpleNamespace(w=sh[0])), 1: SimpleNamespace(P=ps[1], Pb=None, pw=SimpleNamespace(w=sh[1]))}
+        tr = SimpleNamespace(gemms=gemms, affines={0: SimpleNamespace(Pg=ps[3], Pb=ps[4])}, refresh_=lambda shadows_done=False: None)
+        for p in ps:
+            p.grad = torch.zeros_like(p)
+        return ps, sh, tr
+    grads = [torch.randn(*s, generator=g).to(cuda) for s in shapes]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    # reference: one plain step on the mean gradient
+    ps0, sh0, tr0 = make()
+    for p, gr in zip(ps0, grads):
+        p.grad.copy_(gr)
+    o0 = PackedAdamW(tr0, **kw)
+    o0.step()
+    # (a) gate = NaN / inf: nothing moves
+    ps1, sh1, tr1 = make()
+    before = [p.detach().clone() for p in ps1]
+    for p, gr in zip(ps1, grads):
+        p.grad.copy_(gr * 3.0)
+    o1 = PackedAdamW(tr1, **kw)
+    for bad in (float("nan"), float("inf")):
+        o1.step(gate=torch.tensor(bad, device=cuda), grad_scale=1.0 / 3.0)
+        assert all(torch.equal(p.detach(), b) for p, b in zip(ps1, before)) and float(o1.step_t) == 0.0
+        assert all(float(m.abs().max()) == 0.0 for m in o1.m) and float(sh1[0].float().abs().max()) == 0.0
+    # (b) finite gate, gradients summed over 3 "ranks", scale 1/3: the reference step
+    o1.step(gate=torch.tensor(0.25, device=cuda), grad_scale=1.0 / 3.0)
+    assert float(o1.step_t) == 1.0
+    for p, r in zip(ps1, ps0):
+        assert float((p - r).abs().max()) <= 2e-6 * float(r.abs().max())
+    assert torch.equal(sh1[0], ps1[0].detach().to(torch.bfloat16))
+    # (c) two groups, stepped one after the other: bitwise the single launch
+    ps2, sh2, tr2 = make()
+    for p, gr in zip(ps2, grads):
+        p.grad.copy_(gr)
+    ids = {id(p): i for i, p in enumerate(ps2)}
+    o2 = PackedAdamW(tr2, group_of=lambda p: ids[id(p)] % 2, **kw)
+    assert sorted(o2.groups) == [0, 1]
+    o2.step_group(1)
+    o2.step_group(0)
+    o2.finish_step()
+    assert float(o2.step_t) == 1.0 and all(torch.equal(p.detach(), r.detach()) for p, r in zip(ps2, ps0))
+    assert torch.equal(sh2[1], sh0[1])
+
+
+def test_graphed_finetune_step_skips_a_batch_with_nan_loss(cuda):
+    """GraphedFineTunerStep(nan_guard=True): a batch that makes the loss NaN (here: a NaN in the target) is skipped on the
+    device -- parameters, AdamW moments and step count keep their values -- and the following clean batch trains normally
+    (reference: Pruner's "NaNs detected in the loss. Skipping batch.", trainer.py:921-929)."""
+    from diffusion_pruning_amd.train_step import GraphedFineTunerStep, synthetic_batch
+    mask = O.random_mask(O.TINY, 0.6, 9, n_depth_off=1)
+    cfg, sa, sb, teacher = _two_students(cuda, mask)
+    batches = [synthetic_batch(2, 16, cuda, seed=s, cross_dim=cfg.cross_attention_dim) for s in (4, 5, 6)]
+    step = GraphedFineTunerStep(sb, teacher, lr=1e-3, weight_decay=1e-2)
+    step.capture(batches[0])
+    step.train_step(None, batches[0])
+    torch.cuda.synchronize()
+    snap = [p.detach().clone() for p in step.trainer.parameters()]
+    m_snap = [m.clone() for m in step.optimizer.m]
+    assert float(step.optimizer.step_t) == 1.0
+    bad = {k: v.clone() for k, v in batches[1].items()}
+    bad["target"][0, 0, 0, 0] = float("nan")
+    out = step.train_step(None, bad)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out["loss"])
+    assert float(step.optimizer.step_t) == 1.0
+    assert all(torch.equal(p.detach(), s) for p, s in zip(step.trainer.parameters(), snap))
+    assert all(torch.equal(m, s) for m, s in zip(step.optimizer.m, m_snap))
+    out = step.train_step(None, batches[2])
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["loss"]) and float(step.optimizer.step_t) == 2.0
+    moved = sum(float((p.detach() - s).abs().max()) > 0 for p, s in zip(step.trainer.parameters(), snap))
+    assert moved >= len(snap) // 2
+    assert all(torch.isfinite(p).all() for p in step.trainer.parameters())
+
+
+def test_graphed_finetune_data_parallel_schedule_on_one_rank(cuda):
+    """GraphedFineTunerStep(data_parallel=True) with a process group of ONE rank on the GPU backend (RCCL): the gradient arena is
+    exchanged in place (2 collectives per bucket and step, no per-tensor operation) and the step equals the plain graphed step
+    bit for bit (sum over one rank = the gradient, grad_scale = 1)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from diffusion_pruning_amd.train_step import GraphedFineTunerStep, synthetic_batch
+    mask = O.random_mask(O.TINY, 0.6, 9, n_depth_off=1)
+    cfg, sa, sb, teacher = _two_students(cuda, mask)
+    batches = [synthetic_batch(2, 16, cuda, seed=s, cross_dim=cfg.cross_attention_dim) for s in (4, 5, 6)]
+    plain = GraphedFineTunerStep(sa, teacher, lr=1e-3, weight_decay=1e-2)
+    plain.capture(batches[0])
+    la = [float(plain.train_step(None, b)["loss"]) for b in batches]
+    torch.cuda.synchronize()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        dp = GraphedFineTunerStep(sb, teacher, lr=1e-3, weight_decay=1e-2, data_parallel=True, bucket_bytes=1 << 20)
+        dp.capture(batches[0])
+        lb = [float(dp.train_step(None, b)["loss"]) for b in batches]
+        torch.cuda.synchronize()
+        red = dp.reducer
+        assert len(red.buckets) >= 2 and red.stats["steps"] == 3
+        assert red.stats["collectives"] == 2 * len(red.buckets) * 3 and red.stats["tensor_ops"] == 0
+        # every packed gradient is a view into the arena
+        a0, a1 = dp.trainer.grad_arena.data_ptr(), dp.trainer.grad_arena.data_ptr() + dp.trainer.grad_arena.numel() * 4
+        assert all(a0 <= p.grad.data_ptr() < a1 for p in dp.trainer.parameters())
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert la == lb, (la, lb)
+    for pa, pb in zip(plain.trainer.parameters(), dp.trainer.parameters()):
+        assert torch.equal(pa.detach(), pb.detach())

@@ -989,3 +989,76 @@ def test_capture_time_scratch_buffers_are_never_released(ops, cuda):
     g2.replay()                                            # writes through p1: must still be this process's memory
     torch.cuda.synchronize()
     assert bool((kept[0][:1 << 10] == 7).all())
+
+
+LIN_TILES = [12, 18, 25, 49, 9, 15, 24, 51, 11, 17, 26, 53]
+
+
+@pytest.mark.parametrize("tile", LIN_TILES)
+@pytest.mark.parametrize("M,Cin,N,res,ln,silu", [
+    (4096, 320, 640, True, False, False),      # a1_out at level 32: + residual, row statistics out
+    (1000, 160, 328, True, True, False),       # ragged M and N tails, channel padding in the last K-tile, folded LayerNorm
+    (16384, 128, 320, False, False, False),    # short K (2 K-tiles), column statistics for a GroupNorm
+    (300, 1280, 1288, True, True, True),       # long K, 20 producer slot pairs, SiLU
+    (4, 320, 1280, False, False, True),        # time-embedding MLP: four rows
+])
+def test_lean_linear_kernel_equals_the_general_kernel(ops, cuda, tile, M, Cin, N, res, ln, silu):
+    """csrc/lin_gemm.hip (plain linear layers: blocks.py:228-268,776-849) against conv_gemm_dma_kernel on the same tile shape
+    (AptpConvGemmParams.epilogue = 2 keeps the launch on the general kernel) and against fp32 PyTorch: the accumulation order is
+    the same, so y must be bit-identical; row / column statistics may differ by their summation order."""
+    g = torch.Generator().manual_seed(M + Cin + N + tile)
+    H = M
+    x = (_rand((1, H, 1, Cin), g)).bfloat16().to(cuda)
+    w = _rand((N, Cin, 1, 1), g, 1.0 / math.sqrt(Cin))
+    b = _rand((N,), g, 0.1)
+    r = _rand((1, H, 1, N), g).bfloat16().to(cuda) if res else None
+    kw = dict(tile=tile, residual=r, act=ops.ACT_SILU if silu else ops.ACT_NONE, pad=0)
+    if ln:
+        gamma, beta = torch.rand(Cin, generator=g) + 0.5, _rand((Cin,), g, 0.1)
+        pw = ops.pack_weight(w, b, device=cuda, ln_gamma=gamma, ln_beta=beta)
+        xs = x.float().reshape(M, Cin)
+        npair = 3 if Cin < 1000 else 20            # statistics split over several producer slots (zeros in the rest of a pair)
+        st = torch.zeros(npair, M, 4, dtype=torch.float32, device=cuda)
+        cuts = torch.linspace(0, Cin, 2 * npair + 1).long().tolist()
+        for s in range(2 * npair):
+            seg = xs[:, cuts[s]:cuts[s + 1]]
+            st[s // 2, :, 2 * (s % 2)] = seg.sum(1)
+            st[s // 2, :, 2 * (s % 2) + 1] = (seg * seg).sum(1)
+        kw["ln"] = (st, 1e-5)
+    else:
+        pw = ops.pack_weight(w, b, device=cuda)
+    ops.EPILOGUE = 2
+    try:
+        y_ref, st_ref = ops.conv_gemm(x, pw, rowstats=True, **kw)
+    finally:
+        ops.EPILOGUE = 0
+    y, st_new = ops.conv_gemm(x, pw, rowstats=True, colstats=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+    assert st_new is not None and st_new.shape == st_ref.shape
+    yf = y.float().reshape(M, N)
+    tot = st_new.sum(0)                                # [M, 4] -> (sum, sumsq) pairs of all slots
+    assert torch.allclose(tot[:, 0] + tot[:, 2], yf.sum(1), rtol=1e-4, atol=2e-2)
+    assert torch.allclose(tot[:, 1] + tot[:, 3], (yf * yf).sum(1), rtol=1e-4, atol=2e-2)
+    assert torch.allclose(st_new, st_ref, rtol=1e-4, atol=2e-2)
+    # fp32 reference on the same bf16 operands
+    xf = x.float().reshape(M, Cin).cpu()
+    wf = (w.reshape(N, Cin) * (gamma[None, :] if ln else 1.0)).bfloat16().float()
+    if ln:
+        pre = (F.layer_norm(xf, (Cin,), gamma, beta, 1e-5) - beta) / gamma
+        ref = pre @ wf.t() + (b + w.reshape(N, Cin) @ beta)
+    else:
+        ref = xf @ wf.t() + b
+    if silu:
+        ref = F.silu(ref)
+    if res:
+        ref = ref + r.float().reshape(M, N).cpu()
+    assert rel_l2(yf.cpu(), ref) <= REL_L2_TOL
+    # column statistics (GroupNorm producer side) where the launch could emit them
+    rec = ops._colstats_get(y, N) if (H >= ops.COLSTATS_MIN_HW) else None
+    if rec is not None:
+        cst, rpb = rec[0][0].float(), rec[0][1]
+        nb = M // rpb
+        yb = yf[:nb * rpb].reshape(nb, rpb, N)
+        assert torch.allclose(cst[:nb, :, 0], yb.sum(1), rtol=1e-4, atol=2e-2)
+        assert torch.allclose(cst[:nb, :, 1], (yb * yb).sum(1), rtol=1e-4, atol=2e-2)

@@ -44,6 +44,8 @@ Prints ONE JSON line (see the task contract) with extra objects:
                   torch.matmul, and this repo's own kernel) and a 1 GiB device copy; per_tile = the same fraction for each
                   kernel instantiation.
   roofline_groupnorm  HBM roofline of the GroupNorm(+SiLU) family: algorithmic bytes (x read once + y written once) / time.
+  gpu_vendor_baseline  the oracle's op sequence on this GPU in bf16 through torch-ROCm's own libraries (MIOpen / hipBLASLt / SDPA),
+                  gated semantics, HIP-graph replay (tools/bench_vendor.py, child process): a stated yardstick, not the target.
   cpu_baseline    the oracle (PyTorch CPU restatement, fp32) timed on this host's cores on a bounded sample: median of 5
                   steps of the headline workload (bs=4, masked) and of BASELINE configs[0] (bs=1, dense).
 """
@@ -74,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--expert-offset", type=int, default=None, help="(finetune) rank r trains expert (r + offset) %% 8; default 3 at N = 1, else 0")
     ap.add_argument("--data-parallel", action="store_true", help="(finetune) all ranks train ONE expert (expert --expert-offset), gradients "
                     "summed in place over the gradient arena (train_step.ArenaGradReducer), mean folded into AdamW")
+    ap.add_argument("--no-vendor-baseline", action="store_true", help="(infer) skip the torch-ROCm vendor-library yardstick (gpu_vendor_baseline)")
     ap.add_argument("--no-extra-configs", action="store_true", help="(infer) skip the train / finetune measurements that follow the headline")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="(infer) length of the sustained-replay leg; 0 = off")
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
@@ -268,7 +271,7 @@ def run_infer(R: Rank):
     def step():
         return model(sample, t, ehs, return_dict=False)[0]
 
-    roofline = roofline_gn = cpu_baseline = None
+    roofline = roofline_gn = cpu_baseline = vendor_baseline = None
     with torch.no_grad():
         out = step()                      # builds the packed-weight plans
         R.sync()
@@ -307,6 +310,18 @@ def run_infer(R: Rank):
             roofline_gn = measure_gn_roofline(ops, step, dev)
             if R.world == 1 and not args.no_cpu_baseline:
                 cpu_baseline = measure_cpu_baseline(model, args.dense)
+            if R.world == 1 and not args.no_vendor_baseline and L == 64:
+                vendor_baseline = measure_vendor_baseline(B, args.dense)
+    infer_bs16 = None
+    if R.rank == 0 and R.world == 1 and not R.cpu and not args.no_extras and not args.no_extra_configs and L == 64 and B == 4:
+        # the reference's own evaluation operating point: U-Net batch 16 = 8 prompts x classifier-free guidance
+        # (configs/img_generation/sd-2-1_cc3m.yaml:47,50, scripts/metrics/generate_fid_images.py:104-128); same model, same mask
+        try:
+            infer_bs16 = measure_infer_batch(torch, ops, model, dev, 16, L, xdim, masked=not args.dense)
+        except Exception as e:  # noqa: BLE001   (never lose the headline line to an extra)
+            import traceback
+            infer_bs16 = {"error": repr(e), "where": traceback.format_exc()[-500:]}
+        torch.cuda.empty_cache()
     extra_configs = None
     if R.rank == 0 and R.world == 1 and not R.cpu and not args.no_extras and not args.no_extra_configs and L == 64:
         # BASELINE configs[2] and configs[4] in the same record (the driver runs only this default command): measured after
@@ -336,6 +351,9 @@ def run_infer(R: Rank):
             torch.cuda.empty_cache()
     if R.rank != 0:
         return None
+    if infer_bs16 is not None:
+        extra_configs = dict(extra_configs or {})
+        extra_configs["infer_bs16"] = infer_bs16
     what = "mask=1" if args.dense else "fixed 50% mask (gated semantics)"
     line = {
         "metric": "denoise-steps/s (SD-2.1 U-Net forward, 512x512, bs=4 per GPU, " + ("dense)" if args.dense else "50% channel mask)"),
@@ -347,6 +365,7 @@ def run_infer(R: Rank):
                    "global_batch": B * R.world, "parallelism": f"replicas x{R.world} (no data-path collective)"},
         "per_gpu_steps_per_s": round(value / R.world, 3),
         "roofline": roofline, "roofline_groupnorm": roofline_gn, "cpu_baseline": cpu_baseline,
+        "gpu_vendor_baseline": vendor_baseline,
         "sustained": sustained, "extra_configs": extra_configs,
     }
     return line
@@ -684,6 +703,56 @@ def measure_sustained(replay, seconds: float, headline_value: float, local_rank:
     return out
 
 
+def measure_infer_batch(torch, ops, model, dev, batch, latent, xdim, steps=10, warmup=2, masked=True):
+    """the same forward at another U-Net batch, graph-replayed: steps/s, latents/s, the conv_gemm family's MFMA roofline inside it
+    and how much of the family runs on the persistent stream-K macro-tiles (APTP_TILE_SK_*, csrc/conv_gemm_sk.hip)"""
+    g = torch.Generator().manual_seed(4321)
+    sample = torch.randn(batch, 4, latent, latent, generator=g).to(dev)
+    ehs = torch.randn(batch, 77, xdim, generator=g).to(dev)
+    t = torch.full((batch,), 500, dtype=torch.int64, device=dev)
+
+    def step():
+        return model(sample, t, ehs, return_dict=False)[0]
+    with torch.no_grad():
+        out = step()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gout = step()
+        for _ in range(warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        assert torch.isfinite(gout).all()
+        roof = measure_roofline(ops, step, dev, per_tile=True)
+    sk = {k: v for k, v in roof["per_tile"].items() if k.isdigit() and int(k) >= ops.SK_TILE_FIRST}
+    sk_ms = sum(v["ms"] for v in sk.values())
+    flops = algorithmic_flops(masked, batch, latent) if latent == 64 else None
+    del graph, gout
+    return {"config": f"the headline model and mask at U-Net batch {batch} (the reference's evaluation batch: 8 prompts x CFG), HIP graph replay",
+            "value": round(1e3 / ms, 3), "unit": "steps/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+            "latents_per_s": round(batch * 1e3 / ms, 1),
+            "whole_step_tflops": None if flops is None else round(flops / (ms * 1e-3) / 1e12, 1),
+            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "family_ms_per_step",
+                                              "algorithmic_gflop_per_step")},
+            "stream_k": {"launches": sum(v["launches"] for v in sk.values()), "ms": round(sk_ms, 4),
+                         "share_of_family_time": round(sk_ms / roof["family_ms_per_step"], 4) if roof["family_ms_per_step"] else None,
+                         "per_tile": sk},
+            "per_tile": roof["per_tile"]}
+
+
 def measure_roofline(ops, step, dev, per_tile: bool = True):
     """Device time of every conv_gemm launch of one forward (the dominant kernel family), measured with HIP events on
     the launch stream around a HIP graph that replays exactly those launches; then the same per kernel instantiation."""
@@ -800,6 +869,25 @@ def measure_peaks(ops, dev):
     gbs = 2.0 * src.numel() / t(lambda: dst.copy_(src), 10) / 1e9
     return {"gemm_bf16_8192_hipblaslt_tflops": round(lib_tf, 1), "gemm_bf16_8192_own_kernel_tflops": round(own_tf, 1),
             "stream_copy_1GiB_GBs": round(gbs, 1)}
+
+
+def measure_vendor_baseline(batch, dense, budget_s: float = 150.0):
+    """Same-node vendor-library yardstick (stated baseline, not the target): tools/bench_vendor.py in a child process -- the oracle's
+    op sequence on this GPU in bf16 through torch-ROCm's MIOpen / hipBLASLt / SDPA, gated semantics (dense compute + mask
+    multiply, as the reference's UNet2DConditionModelGated does), HIP-graph replay.  Bounded: the child is given `budget_s`."""
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_vendor.py"), "--batch", str(batch)]
+    if dense:
+        cmd.append("--dense")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
+        last = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not last:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        return json.loads(last[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"not finished within {budget_s:.0f} s (library kernel selection on a fresh box)"}
+    except Exception as e:  # noqa: BLE001   (never lose the headline line to a baseline)
+        return {"error": repr(e)}
 
 
 def measure_cpu_baseline(model, dense):

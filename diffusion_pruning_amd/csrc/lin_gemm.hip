@@ -18,7 +18,8 @@
 //     activation and residual there, stores whole 128-byte lines and emits the row / column statistics -- one LDS round
 //     trip and no global-memory wait inside the epilogue;
 //   * the next-launch weight prefetch takes its slice bounds from the host (no division on the device).
-// Anything else (split-K, GEGLU, gates, depth lerp, fp32 I/O, second operand) stays with conv_gemm_dma_kernel.
+// GEGLU projections (ff.net[0]) take the same path with value and gate columns read side by side in the transposed domain.
+// Anything else (split-K, gates, depth lerp, fp32 I/O, second operand) stays with conv_gemm_dma_kernel.
 #include "conv_gemm_core.h"
 
 namespace {
@@ -29,7 +30,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_lin_zero_page[8192];
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KU>
+template <int BM, int BN, int WM, int WN, int STAGES, int KU, bool GEGLU = false>
 __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p) {
   constexpr int NW = WM * WN, NT = NW * 64, RPP = NT / 8;      // RPP: tile rows one LDS-DMA pass of the workgroup covers
   constexpr int WTM = BM / WM, WTN = BN / WN, MF = WTM / 16, NF = WTN / 16;
@@ -38,7 +39,10 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
   static_assert(BM % RPP == 0 && BN % RPP == 0 && WTM % 16 == 0 && WTN % 32 == 0, "tile shape");
   static_assert(STAGES % KU == 0 && D >= KU && NLD * (D - KU) <= 63, "ring");
   // transposed epilogue domain: LPR lanes share a row (8 columns each), RPW rows per pass, NPASS passes over the wave's WTM rows
-  constexpr int LPR = WTN / 8, RPW = 64 / LPR, NPASS = WTM / RPW, PITCH = WTN + 4;
+  // (GEGLU: the packed weight rows interleave value / gate columns in blocks of 16, so a wave's WTN packed columns are WTN / 2
+  //  logical ones; a lane reads its 8 value columns and the 8 gate columns 16 packed columns further on)
+  constexpr int WL = GEGLU ? WTN / 2 : WTN;                     // logical (stored) columns of a wave
+  constexpr int LPR = WL / 8, RPW = (64 / LPR) < WTM ? (64 / LPR) : WTM, NPASS = WTM / RPW, PITCH = WTN + 4;
   static_assert((LPR & (LPR - 1)) == 0 && WTM % RPW == 0, "transposed layout");
   static_assert(NW * WTM * PITCH * 4 <= STAGES * (BM + BN) * BK * 2, "epilogue transpose buffer");
 
@@ -121,9 +125,12 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
 
   // ---- everything the epilogue will read, requested now (transposed domain: lane -> row lrow of a pass, columns c0 .. c0+7) ----
   const int lrow = lane / LPR, lc8 = lane - lrow * LPR;
-  const int c0 = n0 + wn * WTN + lc8 * 8;
-  const bool col_on = c0 < p.Nout;
-  const int c0c = col_on ? c0 : p.Nout - 8;
+  const int c0 = (GEGLU ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN)) + lc8 * 8;          // first logical column of this lane
+  const bool col_on = c0 < p.Nout && lrow < RPW;
+  const int c0c = c0 < p.Nout ? c0 : p.Nout - 8;
+  // packed column of this lane's 8 value columns (GEGLU: block of 32 = 16 value + 16 gate columns)
+  const int pc = GEGLU ? ((c0c >> 4) * 32 + (c0c & 15)) : c0c;
+  const int bofs = GEGLU ? ((lc8 >> 1) * 32 + (lc8 & 1) * 8) : lc8 * 8;                 // same, relative to the wave's LDS columns
   int mrow[NPASS];
   u32x4 rres[NPASS];
 #pragma unroll
@@ -138,16 +145,26 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
   }
   float4 bia[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   float4 csm[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  float4 biag[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  float4 csmg[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   if (p.bias) {
-    bia[0] = *reinterpret_cast<const float4*>(p.bias + c0c);
-    bia[1] = *reinterpret_cast<const float4*>(p.bias + c0c + 4);
+    bia[0] = *reinterpret_cast<const float4*>(p.bias + pc);
+    bia[1] = *reinterpret_cast<const float4*>(p.bias + pc + 4);
+    if constexpr (GEGLU) {
+      biag[0] = *reinterpret_cast<const float4*>(p.bias + pc + 16);
+      biag[1] = *reinterpret_cast<const float4*>(p.bias + pc + 20);
+    }
   }
   float ln_mean[NPASS], ln_rstd[NPASS];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) { ln_mean[ps] = 0.f; ln_rstd[ps] = 1.f; }
   if (p.ln_stats) {
-    csm[0] = *reinterpret_cast<const float4*>(p.ln_colsum + c0c);
-    csm[1] = *reinterpret_cast<const float4*>(p.ln_colsum + c0c + 4);
+    csm[0] = *reinterpret_cast<const float4*>(p.ln_colsum + pc);
+    csm[1] = *reinterpret_cast<const float4*>(p.ln_colsum + pc + 4);
+    if constexpr (GEGLU) {
+      csmg[0] = *reinterpret_cast<const float4*>(p.ln_colsum + pc + 16);
+      csmg[1] = *reinterpret_cast<const float4*>(p.ln_colsum + pc + 20);
+    }
     // producer partials [npair][M] x (sum, sumsq, sum, sumsq): the LPR lanes of a row take pairs lc8, lc8 + LPR, ...
     const float4* sp = reinterpret_cast<const float4*>(p.ln_stats);
     const int npair = p.ln_slots >> 1;
@@ -269,13 +286,18 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
   const int slot = tn * WN + wn;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
-    const int r = ps * RPW + lrow, m2 = m0 + wm * WTM + r;
+    const int r = (ps * RPW + lrow) < WTM ? (ps * RPW + lrow) : 0, m2 = m0 + wm * WTM + r;
     const bool on = col_on && m2 < p.M;
-    float v[8];
+    float v[8], gt[8];
     {
-      const float4 a = *reinterpret_cast<const float4*>(buf + r * PITCH + lc8 * 8);
-      const float4 b = *reinterpret_cast<const float4*>(buf + r * PITCH + lc8 * 8 + 4);
+      const float4 a = *reinterpret_cast<const float4*>(buf + r * PITCH + bofs);
+      const float4 b = *reinterpret_cast<const float4*>(buf + r * PITCH + bofs + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    if constexpr (GEGLU) {
+      const float4 a = *reinterpret_cast<const float4*>(buf + r * PITCH + bofs + 16);
+      const float4 b = *reinterpret_cast<const float4*>(buf + r * PITCH + bofs + 20);
+      gt[0] = a.x; gt[1] = a.y; gt[2] = a.z; gt[3] = a.w; gt[4] = b.x; gt[5] = b.y; gt[6] = b.z; gt[7] = b.w;
     }
     const float cb[8] = {bia[0].x, bia[0].y, bia[0].z, bia[0].w, bia[1].x, bia[1].y, bia[1].z, bia[1].w};
     if (p.ln_stats) {
@@ -283,9 +305,20 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
       const float cc[8] = {csm[0].x, csm[0].y, csm[0].z, csm[0].w, csm[1].x, csm[1].y, csm[1].z, csm[1].w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ln_rstd[ps] * (v[e] - ln_mean[ps] * cc[e]);
+      if constexpr (GEGLU) {
+        const float cg[8] = {csmg[0].x, csmg[0].y, csmg[0].z, csmg[0].w, csmg[1].x, csmg[1].y, csmg[1].z, csmg[1].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gt[e] = ln_rstd[ps] * (gt[e] - ln_mean[ps] * cg[e]);
+      }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += cb[e];
+    if constexpr (GEGLU) {
+      // ff.net[0] (GEGLU, blocks.py:776-849 / diffusers GEGLU): value * gelu(gate), both halves with their own bias
+      const float cbg[8] = {biag[0].x, biag[0].y, biag[0].z, biag[0].w, biag[1].x, biag[1].y, biag[1].z, biag[1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * gelu_erf_f(gt[e] + cbg[e]);
+    } else
     if (p.act == APTP_ACT_SILU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
@@ -321,7 +354,7 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
       }
     }
   }
-  if (p.cstat_out) {
+  if (!GEGLU && p.cstat_out) {
     // GroupNorm statistics for the consumer of y: per channel, (sum, sumsq) over the WTM rows this wave stored; the RPW lanes
     // that hold the same 8-column chunk are folded through the wave's LDS slice (fixed order: deterministic)
     static_assert(RPW * WTN <= WTM * PITCH, "column-statistics staging");
@@ -363,6 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
 
 template <int BM, int BN, int WM, int WN, int STAGES, int KU>
 void launch_lin(KParams k, hipStream_t s) {
+  const bool geglu = k.act == APTP_ACT_GEGLU;
   const int tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
   // next-launch prefetch: slice bounds on the host (lines of the xcd-th eighth per workgroup of that XCD; aptp_prefetch_slice)
   k.pf_lines = 0; k.pf_per = 0;
@@ -373,7 +407,8 @@ void launch_lin(KParams k, hipStream_t s) {
     k.pf_per = (per_xcd + nper - 1) / nper;
     if (k.pf_per < 1) k.pf_per = 1;
   }
-  hipLaunchKernelGGL((lin_gemm_kernel<BM, BN, WM, WN, STAGES, KU>), dim3(tiles), dim3(WM * WN * 64), 0, s, k);
+  if (geglu) hipLaunchKernelGGL((lin_gemm_kernel<BM, BN, WM, WN, STAGES, KU, true>), dim3(tiles), dim3(WM * WN * 64), 0, s, k);
+  else hipLaunchKernelGGL((lin_gemm_kernel<BM, BN, WM, WN, STAGES, KU, false>), dim3(tiles), dim3(WM * WN * 64), 0, s, k);
 }
 
 }  // namespace
@@ -385,7 +420,8 @@ namespace aptp_cg {
 bool aptp_lin_eligible(const KParams& k, int tile) {
   if (k.KH != 1 || k.KW != 1 || k.stride != 1 || k.pad != 0 || k.ups != 0 || k.zins || k.x2 || k.ncc2) return false;
   if (k.split_k != 1 || k.io_f32 || k.out_f32 || !k.epi16 || k.gn_gamma) return false;
-  if (k.act == APTP_ACT_GEGLU || k.colgate || k.corr || k.rowbias || k.depth) return false;
+  if (k.colgate || k.corr || k.rowbias || k.depth) return false;
+  if (k.act == APTP_ACT_GEGLU && (k.residual || k.rstat_out || k.cstat_out || k.N % 32 != 0)) return false;
   if (k.Nout < 8 || k.ncc < 1) return false;
   switch (tile) {
     case APTP_TILE_DMA_64x64: case APTP_TILE_DMA3_64x64: case APTP_TILE_DMA4_64x64: case APTP_TILE_DMA6_64x64: case APTP_TILE_DMA8S_64x64:

@@ -1062,3 +1062,43 @@ def test_lean_linear_kernel_equals_the_general_kernel(ops, cuda, tile, M, Cin, N
         yb = yf[:nb * rpb].reshape(nb, rpb, N)
         assert torch.allclose(cst[:nb, :, 0], yb.sum(1), rtol=1e-4, atol=2e-2)
         assert torch.allclose(cst[:nb, :, 1], (yb * yb).sum(1), rtol=1e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("tile", LIN_TILES)
+@pytest.mark.parametrize("M,C,inner", [(4096, 640, 1280), (1000, 160, 200), (256, 1280, 2560)])
+def test_lean_geglu_projection_equals_the_general_kernel(ops, cuda, tile, M, C, inner):
+    """ff.net[0] (GEGLU with the LayerNorm folded in, blocks.py:776-849) through csrc/lin_gemm.hip: bit-identical to the general
+    kernel on the same tile shape up to the FMA contraction of the activation chain (<= 1 bf16 ulp on <= 0.2 % of the outputs), and
+    within the per-op tolerance of fp32 PyTorch on the same bf16 operands."""
+    g = torch.Generator().manual_seed(M + C + inner + tile)
+    x = (_rand((1, M, 1, C), g) * 1.5).bfloat16().to(cuda)
+    w1 = _rand((2 * inner, C), g, 1.0 / math.sqrt(C))
+    b1 = _rand((2 * inner,), g, 0.1)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, _rand((C,), g, 0.1)
+    pw = ops.pack_weight(w1, b1, geglu=True, device=cuda, ln_gamma=gamma, ln_beta=beta)
+    xs = x.float().reshape(M, C)
+    st = torch.zeros(2, M, 4, dtype=torch.float32, device=cuda)
+    h = C // 3 // 8 * 8
+    for s_, (a, b) in enumerate(((0, h), (h, 2 * h), (2 * h, C))):
+        st[s_ // 2, :, 2 * (s_ % 2)] = xs[:, a:b].sum(1)
+        st[s_ // 2, :, 2 * (s_ % 2) + 1] = (xs[:, a:b] * xs[:, a:b]).sum(1)
+    ops.EPILOGUE = 2
+    try:
+        y_ref = ops.conv_gemm(x, pw, tile=tile, pad=0, ln=(st, 1e-5))
+    finally:
+        ops.EPILOGUE = 0
+    y = ops.conv_gemm(x, pw, tile=tile, pad=0, ln=(st, 1e-5))
+    torch.cuda.synchronize()
+    assert y.shape[-1] == pw.N // 2
+    # same accumulators; the h * gelu(g) chain may be contracted into FMAs differently by the compiler in the two epilogues, so a
+    # few outputs land on the other side of a bf16 rounding boundary: at most one ulp, and rarely
+    a, b = y.float(), y_ref.float()
+    diff = (a - b).abs()
+    assert bool((diff <= torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-6).all()), float(diff.max())
+    assert float((diff > 0).float().mean()) <= 2e-3
+    xf = xs.cpu()
+    pre = (F.layer_norm(xf, (C,), gamma, beta, 1e-5) - beta) / gamma
+    w1f = (w1 * gamma[None, :]).bfloat16().float()
+    hg = pre @ w1f.t() + (b1 + w1 @ beta)
+    ref = hg[:, :inner] * F.gelu(hg[:, inner:])
+    assert rel_l2(y.float().reshape(M, -1)[:, :inner].cpu(), ref) <= REL_L2_TOL

@@ -329,3 +329,34 @@ def test_captured_graph_survives_other_masks_passing_through_the_plan_caches(sd2
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(gout, want)
+
+
+def test_config1_half_mask_bs16_the_reference_evaluation_batch_on_streamk_tiles(sd21, cuda):
+    """U-Net batch 16 (8 prompts x classifier-free guidance: configs/img_generation/sd-2-1_cc3m.yaml:47,50,
+    scripts/metrics/generate_fid_images.py:104-128) -- the operating point where the persistent stream-K macro-tiles
+    (csrc/conv_gemm_sk.hip, ops.SK_AUTO) take the large contractions of a whole forward: parity against the oracle, and the
+    launches really are on those tiles."""
+    from diffusion_pruning_amd import ops
+    model, params = sd21
+    cfg = O.SD21
+    B = 16
+    sample, t, ehs = O.synthetic_inputs(cfg, B, 64, seed=123)
+    mask = O.fixed_half_mask(cfg)
+    assert ops.SK_AUTO
+    with torch.no_grad():
+        ref = O.unet_forward(params, cfg, sample, t, ehs, O.assign_gates(cfg, {k: [v.clone() for v in vs] for k, vs in mask.items()}), "gated")
+        model.set_structure({k: [v.to(cuda) for v in vs] for k, vs in mask.items()})
+        s, tt, e_ = sample.to(cuda), t.to(cuda), ehs.to(cuda)
+        model(s, tt, e_)
+        ops.LAUNCH_LOG = []
+        try:
+            out = model(s, tt, e_).sample
+            torch.cuda.synchronize()
+            log = ops.LAUNCH_LOG
+        finally:
+            ops.LAUNCH_LOG = None
+    n_sk = sum(1 for r in log if "fn" not in r and r["params"].tile >= ops.SK_TILE_FIRST)
+    assert n_sk >= 8, n_sk
+    check(rel_l2(out.float().cpu(), ref), 2e-2, f"bs=16 forward, {n_sk} launches on stream-K macro-tiles")
+    per = [rel_l2(out[i].float().cpu(), ref[i]) for i in range(B)]
+    assert max(per) <= 2.2e-2, per

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--wide", type=int, default=0, help="also shortlist the N fastest (isolated, warm) of ALL (tile, split-K, order) "
                     "combinations per shape and evaluate those in situ")
     ap.add_argument("--apply", action="store_true", help="also write the merged table over the package's own (for chained runs in one job)")
+    ap.add_argument("--lean", action="store_true", help="round 4: visit only the plain linear layers (1x1, stride 1) and try every tile the lean "
+                    "kernel of csrc/lin_gemm.hip instantiates (one K-slice), in both XCD orders for the best one")
     args = ap.parse_args()
     t_start = time.time()
     ops._lib.load()
@@ -114,7 +116,12 @@ def main():
         key = ops.tuning_key(p.B * p.Hout * p.Wout, p.N, p.Cin, p.KH * p.KW, p.stride, p.ups, p.act == ACT_GEGLU, p.Cin2 if p.x2 else 0)
         s = shapes.setdefault(key, {"count": 0, "flops": rec["flops"], "params": p})
         s["count"] += 1
-    order = sorted(shapes, key=lambda k: -shapes[k]["flops"] * shapes[k]["count"] ** 0.5)[:args.top]
+    LEAN_TILES = (12, 18, 25, 49, 9, 15, 24, 51, 11, 17, 26, 53)
+    order = sorted(shapes, key=lambda k: -shapes[k]["flops"] * shapes[k]["count"] ** 0.5)
+    if args.lean:
+        order = [k for k in order if int(KEY.match(k).group(4)) == 1 and int(KEY.match(k).group(5)) == 1 and int(KEY.match(k).group(1)) >= 256]
+        order.sort(key=lambda k: -shapes[k]["count"] * (shapes[k]["flops"] ** 0.5))
+    order = order[:args.top]
 
     def cls(key):
         m = KEY.match(key)
@@ -222,6 +229,9 @@ def main():
             cands.add((inc[0], inc[1], o, inc[3]))
         if args.wide:
             cands.update(wide_shortlist(key, nK, args.wide))
+        if args.lean:
+            cands = {(t_, 1, inc[2], 0) for t_ in LEAN_TILES}
+            cands.update({(t_, 1, 5 - inc[2] if inc[2] in (2, 3) else 3, 0) for t_ in (12, 18, 49, 9, 11)})
         cands.discard(inc)
         cands = [cd for cd in cands if not (cd[1] > 1 and nK // cd[1] < 3)][:28 + args.wide]
         best, best_v = inc, base

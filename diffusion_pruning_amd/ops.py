@@ -217,6 +217,8 @@ TUNING = _load_tuning()
 TUNING_NEAREST = os.environ.get("APTP_TUNING_NEAREST", "1") != "0"
 TUNING_MAX_DIST = 2.0
 _HALO_TILES = (43, 44)
+_LEAN_TILES = (9, 11, 12, 15, 17, 18, 24, 25, 26, 45, 46, 47, 48, 49, 50, 51, 52, 53)     # tiles csrc/lin_gemm.hip instantiates (aptp_lin_eligible)
+LEAN_REMAP = os.environ.get("APTP_LEAN_REMAP", "1") != "0"
 SK_TILE_FIRST = 64          # APTP_TILE_SK_*: persistent stream-K macro-tiles (csrc/conv_gemm_sk.hip)
 SK_AUTO = os.environ.get("APTP_SK_AUTO", "1") == "1"
 SK_AUTO_MIN_OUTPUTS = 256 * 256 * 160
@@ -585,6 +587,14 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
             in_kernel = bool(tuned.get("in_kernel", 0))
+            if LEAN_REMAP and p.tile not in _LEAN_TILES and split_k == 1 and "insitu" not in tuned and pw.KH == 1 and pw.KW == 1 \
+                    and stride == 1 and not ups and x2 is None and colgate is None and corr is None and rowbias is None \
+                    and depth is None and not out_f32 and gn is None and (act != ACT_GEGLU or (residual is None and not rowstats)):
+                # a plain linear layer whose table entry (tuned before csrc/lin_gemm.hip existed: the training steps' shapes) names a
+                # tile the lean kernel has no instantiation of -- the 160-wide and the intra-workgroup K-split tiles: take the lean
+                # tile the in-situ pass over the inference forward preferred at this row count (profiles/r4_tune_insitu_lean.txt)
+                M_ = B * Hout * Wout
+                p.tile = 11 if M_ >= 8192 else (18 if M_ >= 2048 else 49)
             if order == 0:
                 p.order = tuned.get("order", 1)     # tables tuned before the XCD-aware orders existed mean the legacy order
     if split_k is None and tile == 0 and p.tile == 0 and SK_AUTO and not f32:
@@ -797,7 +807,12 @@ GN_REDUCE_MAX_HW = 256
 # per 64-token tile.  Worth it only where a row tile per CU fills the chip and the activations, not the weights, are the
 # bytes that matter: M >= FUSE_TAIL_MIN_ROWS (SD-2.1 level 64 at bs >= 4).  APTP_FUSE_TAIL=0 disables; APTP_FUSE_TAIL_MIN_ROWS
 # moves the threshold (tests exercise the kernel on small maps).
-FUSE_TAIL = os.environ.get("APTP_FUSE_TAIL", "1") != "0"
+# Round 4: OFF by default.  With the lean linear kernel (csrc/lin_gemm.hip) the three separate launches are faster than the
+# fused tile (same-box A/B on the headline forward: 202.8 steps/s without, 201.6 with; round 2, against the general kernel, the
+# fused tile won by 0.3-0.6 %): one workgroup per CU walks 40 dependent K-steps while the launches keep 3-5 workgroups per CU
+# in different phases.  APTP_FUSE_TAIL=1 turns it back on (tests of the kernel, A/B timing); it still saves 0.8 GB of HBM
+# traffic per step.
+FUSE_TAIL = os.environ.get("APTP_FUSE_TAIL", "0") != "0"
 FUSE_TAIL_MIN_ROWS = int(os.environ.get("APTP_FUSE_TAIL_MIN_ROWS", "16384"))
 
 

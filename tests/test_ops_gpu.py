@@ -888,13 +888,13 @@ def test_ff_tail_fused_kernel(cuda, B, L, C, inner, x_wide):
     pw2 = ops.pack_weight(w2, b2, cin_pad_to=16, device=cuda)
     pw3 = ops.pack_weight(w3, b3, device=cuda)
     h, x = hbuf.to(cuda), xbuf.to(cuda)[..., :C]
-    old_min = ops.FUSE_TAIL_MIN_ROWS
-    ops.FUSE_TAIL_MIN_ROWS = 64
+    old_min, old_fuse = ops.FUSE_TAIL_MIN_ROWS, ops.FUSE_TAIL
+    ops.FUSE_TAIL_MIN_ROWS, ops.FUSE_TAIL = 64, True          # (the fused tail is off by default since round 4)
     try:
         assert ops.ff_tail_supported(h, pw1, pw2, pw3)
         y = ops.ff_tail(h, x, pw1, pw2, pw3, 1e-5, colstats=True)
     finally:
-        ops.FUSE_TAIL_MIN_ROWS = old_min
+        ops.FUSE_TAIL_MIN_ROWS, ops.FUSE_TAIL = old_min, old_fuse
     torch.cuda.synchronize()
     # (a) fp32 reference with the kernel's rounding points (f and h3 are bf16; weights are bf16)
     hf, xf = hbuf.float(), xbuf[..., :C].float()

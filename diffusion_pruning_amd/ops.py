@@ -256,7 +256,11 @@ def tuning_lookup(M, N, Cin, taps, stride, ups, geglu, Cin2: int = 0):
     for (M2, N2, K2, v) in _tuning_classes().get((taps, stride, ups, int(bool(geglu)), Cin2 > 0), ()):
         if v["tile"] in _HALO_TILES and M2 != M:
             continue                      # the halo-in-LDS tiles are tied to the map width
-        d = 1.5 * abs(math.log2(M / M2)) + abs(math.log2(N / N2)) + abs(math.log2(K / K2))
+        # (more rows than the tuned shape is the benign direction -- the same tile, more of them: a U-Net batch of 16 takes the
+        #  entries tuned at batch 4 instead of falling back to the register-staged heuristic tiles, which bench.py's infer_bs16 leg
+        #  measured at 0.08 of the MFMA peak on 48 launches)
+        dm = math.log2(M / M2)
+        d = (0.5 * dm if dm > 0 else -1.5 * dm) + abs(math.log2(N / N2)) + abs(math.log2(K / K2))
         if d < bd:
             best, bd = v, d
     if best is not None:
@@ -582,6 +586,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     explicit_split = split_k is not None
     if split_k is None and tile == 0 and not f32:
         tuned = tuning_lookup(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2)
+        if tuned is not None and SK_AUTO and B * Hout * Wout * pw.N >= SK_AUTO_MIN_OUTPUTS \
+                and pw.KH * pw.KW * (pw.cin_pad // BK) + pw.cin2_pad // BK >= 16 \
+                and tuning_key(B * Hout * Wout, pw.N, Cx, pw.KH * pw.KW, stride, ups, act == ACT_GEGLU, pw.Cin2) not in TUNING:
+            tuned = None                   # only a NEIGHBOUR's entry, and the shape is in the stream-K macro-tiles' range (below)
         if tuned is not None and tuned["tile"] >= 7 and max(pw.cin_pad, pw.cin2_pad) > (32704 if tuned["tile"] >= SK_TILE_FIRST else 4032):
             tuned = None                   # the LDS-DMA tiles address at most 4032 channels per tap (a neighbour's tile may be one)
         if tuned is not None:
@@ -597,6 +605,14 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
                 p.tile = 11 if M_ >= 8192 else (18 if M_ >= 2048 else 49)
             if order == 0:
                 p.order = tuned.get("order", 1)     # tables tuned before the XCD-aware orders existed mean the legacy order
+    if split_k is None and tile == 0 and p.tile == 0 and LEAN_REMAP and not f32 and pw.KH == 1 and pw.KW == 1 and stride == 1 and not ups \
+            and x2 is None and colgate is None and corr is None and rowbias is None and depth is None and not out_f32 and gn is None \
+            and (act != ACT_GEGLU or (residual is None and not rowstats)) and pw.cin_pad <= 4032:
+        # an untuned plain linear layer: a lean tile by row count (csrc/lin_gemm.hip) instead of the library's register-staged pick
+        M_ = B * Hout * Wout
+        p.tile, split_k = (11 if M_ >= 8192 else (18 if M_ >= 2048 else 49)), 1
+        if M_ <= 512 and pw.cin_pad >= 1280:
+            p.tile, split_k = 0, None          # (tiny M with a long K wants a K split: the library heuristic decides)
     if split_k is None and tile == 0 and p.tile == 0 and SK_AUTO and not f32:
         # no table entry: contractions with >= SK_AUTO_MIN_OUTPUTS outputs (a chip-filling number of 256 x 160 macro-tiles) and
         # a long K take the persistent stream-K macro-tiles -- measured 1.28-1.42x the best per-tile launch on such shapes

@@ -88,7 +88,10 @@ def test_every_headline_launch_dma_tile_equals_register_staged_tile(headline_log
         a, b = outs["f32", "dma"].double(), outs["f32", "staged"].double()
         rms = float(b.pow(2).mean().sqrt())
         e32 = float((a - b).abs().max()) / rms
-        assert e32 <= 2e-6 * 8, (what, e32)          # max-norm over up to 10 M elements; the L2 figure is recorded below
+        # max-norm over up to 10 M elements (the L2 figure is recorded below); fp32 re-association error grows with the depth of the
+        # contraction (K = 23,040 under an 8-way split sums in another order than the single slice): sqrt(K) scaling
+        Ktot = p.KH * p.KW * p.Cin + p.Cin2
+        assert e32 <= 2e-6 * 8 * max(1.0, (Ktot / 2048.0) ** 0.5), (what, e32)
         l2 = float((a - b).norm() / b.norm())
         worst32 = max(worst32, l2)
         assert l2 <= 2e-6, (what, l2)

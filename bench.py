@@ -76,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--expert-offset", type=int, default=None, help="(finetune) rank r trains expert (r + offset) %% 8; default 3 at N = 1, else 0")
     ap.add_argument("--data-parallel", action="store_true", help="(finetune) all ranks train ONE expert (expert --expert-offset), gradients "
                     "summed in place over the gradient arena (train_step.ArenaGradReducer), mean folded into AdamW")
+    ap.add_argument("--eager-router", action="store_true", help="(train) keep the router eager between the U-Net graphs (A/B against the captured router)")
     ap.add_argument("--no-vendor-baseline", action="store_true", help="(infer) skip the torch-ROCm vendor-library yardstick (gpu_vendor_baseline)")
     ap.add_argument("--no-extra-configs", action="store_true", help="(infer) skip the train / finetune measurements that follow the headline")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="(infer) length of the sustained-replay leg; 0 = off")
@@ -400,7 +401,8 @@ def run_train(R: Rank, steps=None, warmup=None, extras: bool = True):
     graphed = not (args.no_graph or R.cpu)
     step = (GraphedPrunerStep if graphed else PrunerStep)(unet, hn, qz)
     step.count_macs(latent)
-    opt = torch.optim.AdamW(step.trainable_parameters(), lr=2e-4)
+    # capturable: with one rank the router itself (forward, chain rule, this optimizer) is replayed from HIP graphs too
+    opt = torch.optim.AdamW(step.trainable_parameters(), lr=2e-4, **({} if R.cpu else {"capturable": True}))
     xdim = 1024 if not R.cpu else unet.real.config["cross_attention_dim"]
     batch = synthetic_batch(args.batch, latent, dev, seed=1234 + R.rank, cross_dim=xdim, text_dim=text_dim)   # rank-local shard
     nodes = fam_log = None
@@ -409,7 +411,7 @@ def run_train(R: Rank, steps=None, warmup=None, extras: bool = True):
         graph_utils.KEEP_GRAPHS = True
         ops.LAUNCH_LOG = [] if (extras and R.rank == 0) else None
         try:
-            step.capture(batch)
+            step.capture(batch, optimizer=None if (args.eager_router or R.dist) else opt, pretrain=False)
         finally:
             graph_utils.KEEP_GRAPHS = False
             ops.LAUNCH_LOG = None
@@ -457,7 +459,8 @@ def run_train(R: Rank, steps=None, warmup=None, extras: bool = True):
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[3]" if R.world > 1 else "BASELINE configs[2]") +
                                f": APTP pruning train step, synthetic CC3M-shape batch, bs={args.batch}/GPU, "
-                               + ("U-Net passes replayed from HIP graphs, router eager" if graphed else "eager"),
+                               + (("U-Net passes and the router (forward, chain rule, AdamW; Gumbel noise from the host generator) replayed from HIP graphs"
+                                  if (graphed and step._cap.get("router")) else "U-Net passes replayed from HIP graphs, router eager") if graphed else "eager"),
                    "global_batch": args.batch * R.world,
                    "parallelism": f"dp{R.world}: frozen U-Net replicas; per step 1 fused all-gather [B,768+1620], 1 all-gather of "
                                   "Sinkhorn scores [B,8], 1 flat fp32 all-reduce of 1.26 M router gradients"},

@@ -18,6 +18,50 @@ def sample_gumbel(shape, eps: float = 1e-20, fixed_seed: bool = False) -> torch.
 
 _GATHER_CACHE = {}
 
+# Set by train_step.GraphedPrunerStep while the router is captured into / replayed from HIP graphs: the uniforms of every
+# sample_gumbel_blocks call then live in STATIC device buffers that the host refills from its RNG stream before each replay.
+NOISE_TAPE = None
+
+
+class NoiseTape:
+    """Host-RNG Gumbel noise for a CAPTURED router (reference: the noise is torch.rand on the CPU generator, quirk Q6,
+    pdm/utils/estimation_utils.py:5-10).  A HIP graph cannot draw from the host generator, so every sample_gumbel_blocks call
+    of the captured region is given a static device buffer for its uniforms (entries in call order).  ``refill()`` -- called
+    on the host before each replay -- draws exactly what the eager calls would have drawn, in the same order from the same
+    generator, and uploads it through the pinned ring; the captured kernels (gather into block order, -log(-log u)) then run on
+    the new values.  Inside a stream capture no host draw happens (the buffers hold the warm-up pass's values)."""
+
+    def __init__(self):
+        self.entries = []         # [n, fixed_seed, key, device buffer]
+        self.cursor = 0
+
+    def begin(self):
+        self.cursor = 0
+
+    def uniforms(self, key, n, fixed_seed, device):
+        i = self.cursor
+        self.cursor += 1
+        capturing = torch.cuda.is_current_stream_capturing()
+        if i == len(self.entries):
+            assert not capturing, "NoiseTape: a noise call first seen during capture (run the region eagerly once before capturing)"
+            self.entries.append([n, bool(fixed_seed), key, torch.empty(n, dtype=torch.float32, device=device)])
+        e = self.entries[i]
+        assert e[0] == n and e[1] == bool(fixed_seed), "NoiseTape: the captured region's noise calls changed"
+        if not capturing:
+            self._fill(e)
+        return e[3]
+
+    @staticmethod
+    def _fill(e):
+        gen = torch.Generator().manual_seed(0) if e[1] else None
+        u = torch.rand(e[0], generator=gen)
+        e[3].copy_(_PinnedRing.of(("tape",) + tuple(e[2]), u.shape).send(u, e[3].device))
+
+    def refill(self):
+        """one host draw + upload per recorded call, in call order (the eager path's host-RNG consumption, exactly)"""
+        for e in self.entries:
+            self._fill(e)
+
 
 def sample_gumbel_blocks(batch: int, widths, fixed_seed: bool = False, eps: float = 1e-20, device=None) -> torch.Tensor:
     """cat([sample_gumbel((batch, w)) for w in widths], dim=1), bit for bit, from ONE host draw.
@@ -37,6 +81,13 @@ def sample_gumbel_blocks(batch: int, widths, fixed_seed: bool = False, eps: floa
             off += 0 if fixed_seed else batch * w
         idx = _GATHER_CACHE[key] = torch.cat(cols, dim=1)
     n = batch * (max(widths) if fixed_seed else sum(widths))
+    if NOISE_TAPE is not None and device is not None and torch.device(device).type == "cuda":
+        dkey = key + (str(device),)
+        didx = _GATHER_CACHE.get(dkey)
+        if didx is None:
+            didx = _GATHER_CACHE[dkey] = idx.to(device)
+        u = NOISE_TAPE.uniforms(key, n, fixed_seed, device)[didx]
+        return -torch.log(eps - torch.log(u + eps))
     gen = torch.Generator().manual_seed(0) if fixed_seed else None
     u = torch.rand(n, generator=gen)
     if device is not None and torch.device(device).type == "cuda":

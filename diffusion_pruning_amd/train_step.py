@@ -495,8 +495,13 @@ class GraphedPrunerStep(PrunerStep):
         block_loss = block_loss / len(student_acts)
         return loss, distillation_loss, block_loss
 
-    def capture(self, batch: dict):
-        """Capture both graphs for this batch geometry (call once; later batches must have the same shapes)."""
+    def capture(self, batch: dict, optimizer=None, pretrain: bool = False):
+        """Capture the graphs for this batch geometry (call once; later batches must have the same shapes).
+        optimizer: a CAPTURABLE optimizer over trainable_parameters() (torch.optim.AdamW(..., capturable=True)).  When given
+        (and no process group is initialised: the router's collectives stay eager), the ROUTER is captured too -- hyper-net,
+        quantiser incl. Sinkhorn, Gumbel relaxation, MAC losses as one graph ahead of the student's forward, and the chain rule
+        into the router + the optimizer step as one graph behind the U-Net backward (trainer.py:1129-1138, :922-931) -- for this
+        value of `pretrain`; its Gumbel noise keeps coming from the host generator (estimation_utils.NoiseTape)."""
         cfg = self.cfg
         dev = batch["noisy_latents"].device
         st = {k: batch[k].clone() for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target")}
@@ -597,8 +602,88 @@ class GraphedPrunerStep(PrunerStep):
         # (everything a captured kernel reads must outlive the graphs: `inv` is an operand of the gather that ends g_student_bwd)
         self._cap = dict(st=st, ga=ga, install_code=install_code, perm=perm, inv=inv, full=full, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
                          loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs,
-                         launch_log=launch_log)
+                         launch_log=launch_log, router=None)
+        if optimizer is not None and not (dist.is_available() and dist.is_initialized()):
+            self._capture_router(batch, optimizer, pretrain)
         return self
+
+    # ---- the router as two more graphs ----------------------------------------------------------------------------------
+    def _router_forward(self, text_embeddings, pretrain: bool):
+        """hyper-net -> quantiser -> Gumbel-sigmoid relaxation -> contrastive / MAC losses (step() up to the student's code)"""
+        cfg, cap = self.cfg, self._cap
+        arch_vector = self.hyper_net(text_embeddings)
+        arch_vector_quantized, _ = self.quantizer(arch_vector)
+        arch_vector = self.quantizer.gumbel_sigmoid_trick(arch_vector)
+        arch_vector = self._single_arch_repeat(arch_vector, text_embeddings.shape[0])
+        arch_wdn = self.quantizer.width_depth_normalize(arch_vector)
+        text_all, arch_all = gather_with_local_grad(text_embeddings, arch_wdn)
+        arch_used = arch_vector if pretrain else arch_vector_quantized                          # trainer.py:1165-1168
+        contrastive_loss = self.contrastive(text_all, arch_all)
+        macs = cap["vmacs"](arch_used)
+        ratios = macs["cur_prunable_macs"] / self.unet.resource_info_dict["cur_prunable_macs"].squeeze()
+        resource_loss = self.resource(ratios.mean())
+        max_loss = 1.0 - torch.max(ratios)
+        std_loss = -torch.std(ratios)
+        router_loss = cfg.resource_weight * resource_loss + cfg.contrastive_weight * contrastive_loss \
+            + cfg.std_weight * std_loss + cfg.max_weight * max_loss
+        return dict(arch_used=arch_used, arch_vector_quantized=arch_vector_quantized, contrastive_loss=contrastive_loss,
+                    resource_loss=resource_loss, ratios=ratios, router_loss=router_loss)
+
+    def _capture_router(self, batch, optimizer, pretrain):
+        from . import estimation_utils as EU
+        cap = self._cap
+        assert optimizer.defaults.get("capturable", False), "GraphedPrunerStep.capture(optimizer=): the optimizer must be capturable"
+        params = self.trainable_parameters()
+        text = batch["mpnet_embeddings"].clone()
+        tape = EU.NoiseTape()
+        saved_p = [p.detach().clone() for p in params]
+        host_rng = torch.get_rng_state()
+
+        def fwd():
+            tape.begin()
+            EU.NOISE_TAPE = tape
+            try:
+                r = self._router_forward(text, pretrain)
+            finally:
+                EU.NOISE_TAPE = None
+            with torch.no_grad():
+                cap["install_code"](r["arch_used"])
+            return r
+
+        def bwd(r):
+            ts = [r["arch_used"]] if r["arch_used"].requires_grad else []
+            torch.autograd.backward([r["router_loss"]] + ts, [None] + ([cap["grad"]] if ts else []))
+            optimizer.step()
+
+        # warm-up on a side stream: allocator, caches (gather indices, segment maps), the optimizer's state tensors; then undo it --
+        # parameters, moments and step counts return to their values (in place: their addresses go into the graphs) and the host
+        # generator to its state, so capturing costs the training run nothing
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for p in params:
+                    p.grad = None
+                bwd(fwd())
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, s0 in zip(params, saved_p):
+                p.copy_(s0)
+            for stt in optimizer.state.values():
+                for v in stt.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        for p in params:
+            p.grad = None
+        g_fwd = new_graph()
+        with torch.cuda.graph(g_fwd):
+            r = fwd()
+        g_bwd = new_graph()
+        with torch.cuda.graph(g_bwd, pool=g_fwd.pool()):
+            bwd(r)
+        torch.set_rng_state(host_rng)
+        cap["router"] = dict(g_fwd=g_fwd, g_bwd=g_bwd, out=r, text=text, tape=tape, optimizer=optimizer, pretrain=bool(pretrain))
 
     def graph_nodes(self):
         """nodes (kernel launches + torch's few memcpy / memset nodes) of the three captured graphs, when they were kept
@@ -606,8 +691,12 @@ class GraphedPrunerStep(PrunerStep):
         cap = self._cap
         if cap is None:
             return None
-        return {"teacher": node_count(cap["g_teacher"]), "student_fwd": node_count(cap["g_student"]),
-                "student_bwd": node_count(cap["g_student_bwd"])}
+        n = {"teacher": node_count(cap["g_teacher"]), "student_fwd": node_count(cap["g_student"]),
+             "student_bwd": node_count(cap["g_student_bwd"])}
+        if cap.get("router"):
+            n["router_fwd"] = node_count(cap["router"]["g_fwd"])
+            n["router_bwd_and_optimizer"] = node_count(cap["router"]["g_bwd"])
+        return n
 
     # ---- one step -------------------------------------------------------------------------------------------------------
     def step(self, noisy_latents, timesteps, encoder_hidden_states, text_embeddings, target, pretrain: bool = False):
@@ -675,6 +764,10 @@ class GraphedPrunerStep(PrunerStep):
         torch.autograd.backward([out["_router_loss"]] + ts, [None] + gs)
 
     def train_step(self, optimizer, batch: dict, pretrain: bool = False):
+        cap = self._cap
+        rt = cap.get("router") if cap is not None else None
+        if rt is not None and rt["optimizer"] is optimizer and rt["pretrain"] == bool(pretrain) and self.hyper_net.training:
+            return self._train_step_captured_router(batch)
         optimizer.zero_grad(set_to_none=True)
         out = self.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"],
                         batch["mpnet_embeddings"], batch["target"], pretrain=pretrain)
@@ -682,6 +775,27 @@ class GraphedPrunerStep(PrunerStep):
         allreduce_mean_grads(self.trainable_parameters())
         optimizer.step()
         return out
+
+    def _train_step_captured_router(self, batch: dict):
+        """the whole step from five graphs: [teacher || router] -> student forward -> losses + U-Net backward -> chain rule into the
+        router + optimizer.  The host only stages the batch and refills the Gumbel uniforms from its generator."""
+        cfg, cap = self.cfg, self._cap
+        rt = cap["router"]
+        self._stage_batch_and_launch_teacher(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"], batch["target"])
+        with torch.no_grad():
+            rt["text"].copy_(batch["mpnet_embeddings"])
+        rt["tape"].refill()                                   # host-RNG stream, consumed exactly as the eager calls consume it
+        rt["g_fwd"].replay()                                  # router -> architecture code installed for the student
+        cap["g_student"].replay()
+        torch.cuda.current_stream().wait_stream(cap["side"])
+        cap["g_student_bwd"].replay()
+        rt["g_bwd"].replay()                                  # d(router losses + U-Net terms)/d(router), optimizer step
+        r = rt["out"]
+        unet_loss = cap["loss"] + cfg.distillation_weight * cap["dist"] + cfg.block_weight * cap["blk"]
+        return {"loss": (r["router_loss"].detach() + unet_loss).clone(), "diff_loss": cap["loss"].clone(),
+                "distillation_loss": cap["dist"].clone(), "block_loss": cap["blk"].clone(),
+                "contrastive_loss": r["contrastive_loss"].detach().clone(), "resource_loss": r["resource_loss"].detach().clone(),
+                "resource_ratio": r["ratios"].mean().detach(), "arch_vector_quantized": r["arch_vector_quantized"].detach().clone()}
 
 
 def synthetic_batch(batch: int, latent: int, device, seed: int = 1234, cross_dim: int = 1024, text_dim: int = 768):

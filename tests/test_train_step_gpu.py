@@ -316,3 +316,46 @@ def test_router_has_no_host_synchronisation_and_the_same_values(cuda):
     ref = qz.cpu().gumbel_sigmoid_trick(z.cpu())          # host path: same host-RNG stream, list semantics of index_put
     qz.to(cuda)
     assert torch.allclose(out[:, nw:].cpu(), ref[:, nw:], atol=2e-6) and torch.allclose(out.cpu(), ref, atol=2e-6)
+
+
+def test_captured_router_trains_like_the_eager_router(cuda):
+    """GraphedPrunerStep.capture(optimizer=...) also captures the router (hyper-net, quantiser + Sinkhorn, Gumbel relaxation from the
+    HOST generator through estimation_utils.NoiseTape, MAC losses; chain rule + AdamW behind the U-Net backward: trainer.py:1129-1138,
+    :922-931).  Three training steps on three batches must give the losses and the router parameters of the same steps with the
+    router run eagerly between the graphs -- same host-RNG stream, same arithmetic -- and capturing must cost the run nothing
+    (parameters, optimizer state and generator as before the capture)."""
+    import copy
+    from diffusion_pruning_amd.train_step import GraphedPrunerStep, synthetic_batch
+    cfg, unet, params, hn, qz = build(cuda)
+    unet.to(cuda).freeze()
+    hn.to(cuda); qz.to(cuda)
+    hn.train(); qz.train()
+    hn2, qz2 = copy.deepcopy(hn), copy.deepcopy(qz)
+    batches = [synthetic_batch(4, 16, cuda, seed=s, cross_dim=cfg.cross_attention_dim, text_dim=32) for s in (3, 4, 5)]
+
+    def run(hn_, qz_, captured):
+        step = GraphedPrunerStep(unet, hn_, qz_)
+        step.count_macs(16)
+        opt = torch.optim.AdamW(step.trainable_parameters(), lr=1e-3, capturable=True)
+        p0 = torch.cat([p.detach().flatten().clone() for p in step.trainable_parameters()])
+        torch.manual_seed(77)
+        state0 = torch.get_rng_state()
+        step.capture(batches[0], optimizer=opt if captured else None)
+        assert (step._cap["router"] is not None) == captured
+        assert torch.equal(torch.get_rng_state(), state0)
+        assert torch.equal(torch.cat([p.detach().flatten() for p in step.trainable_parameters()]), p0)
+        losses = []
+        for b in batches:
+            o = step.train_step(opt, b)
+            losses.append({k: float(o[k]) for k in ("loss", "diff_loss", "distillation_loss", "block_loss", "resource_loss", "contrastive_loss")})
+        torch.cuda.synchronize()
+        step.remove_hooks()
+        return losses, torch.cat([p.detach().flatten().clone() for p in step.trainable_parameters()]), p0, step
+
+    la, pa, p0, _ = run(hn, qz, False)
+    lb, pb, _, _ = run(hn2, qz2, True)
+    for a, b in zip(la, lb):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-5, (k, a, b)
+    assert float((pa - p0).abs().max()) > 0
+    assert rel_l2(pb - p0, pa - p0) <= 2e-2, rel_l2(pb - p0, pa - p0)

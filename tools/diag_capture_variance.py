@@ -32,7 +32,11 @@ def analyze(path):
         fills = [(int(r[gkey]) if gkey else 0, i) for i, r in enumerate(rows) if "FillFunctor" in r["Kernel_Name"]]
         top = sorted(sorted(fills)[-3:], key=lambda t: t[1])
         marks = {"fast": top[0][1], "slow": top[1][1], "end": top[2][1]}
+    print("marker rows:", marks, "of", len(rows))
     seg = {"fast": rows[marks["fast"] + 1:marks["slow"]], "slow": rows[marks["slow"] + 1:marks["end"]]}
+    if not seg["fast"] or not seg["slow"]:
+        print("could not split the trace into the two phases")
+        return
 
     def short(n):
         n = re.sub(r"\(anonymous namespace\)::", "", n)

@@ -603,8 +603,8 @@ class GraphedPrunerStep(PrunerStep):
         self._cap = dict(st=st, ga=ga, install_code=install_code, perm=perm, inv=inv, full=full, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
                          loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs,
                          launch_log=launch_log, router=None)
-        if optimizer is not None and not (dist.is_available() and dist.is_initialized()):
-            self._capture_router(batch, optimizer, pretrain)
+        if optimizer is not None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self._capture_router(batch, optimizer, pretrain)       # (`dist` is the distillation loss in this scope)
         return self
 
     # ---- the router as two more graphs ----------------------------------------------------------------------------------

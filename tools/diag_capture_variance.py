@@ -143,19 +143,65 @@ def measure(step, n=15):
     return n / (e0.elapsed_time(e1) * 1e-3)
 
 
+def parts(step, n=10):
+    """device time of the three graphs replayed one after the other (no overlap): which of them carries a slow capture's loss"""
+    cap = step._cap
+    out = []
+    for g in (cap["g_teacher"], cap["g_student"], cap["g_student_bwd"]):
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / n)
+    return out
+
+
+def copy_gbs(nbytes=1 << 30, reps=10):
+    """streaming copy bandwidth of memory allocated NOW (from whatever the driver hands out at this point of the process)"""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    r = 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    pa, pb = a.data_ptr(), b.data_ptr()
+    del a, b
+    return r, pa, pb
+
+
+print("allocator config:", os.environ.get("PYTORCH_HIP_ALLOC_CONF") or os.environ.get("PYTORCH_CUDA_ALLOC_CONF") or "(default)")
+r0 = copy_gbs()
+print(f"1 GiB copy on fresh memory before any capture: {r0[0]:.0f} GB/s (0x{r0[1]:x}, 0x{r0[2]:x})", flush=True)
+torch.cuda.empty_cache()
 res = {}
 A = build("A first capture")
 res["A"] = max(measure(A), measure(A))
 B = build("B (A alive)")
 res["B"] = max(measure(B), measure(B))
+pA = parts(A)
 del A
 gc.collect()
+torch.cuda.empty_cache()
+r1 = copy_gbs()
+print(f"1 GiB copy on memory re-allocated right after A's 12 GiB went back to the driver: {r1[0]:.0f} GB/s (0x{r1[1]:x}, 0x{r1[2]:x})", flush=True)
+torch.cuda.empty_cache()
 C = build("C (A freed, B alive)")
 res["C"] = max(measure(C), measure(C))
 junk = [torch.empty(int(1.3 * 2 ** 30), dtype=torch.uint8, device=dev) for _ in range(3)]
 D = build("D (after 3.9 GiB of other allocations)")
 res["D"] = max(measure(D), measure(D))
 steps = {"B": B, "C": C, "D": D}
+print("per-graph ms (teacher, student fwd, student bwd), replayed alone: A " + " ".join(f"{v:.2f}" for v in pA) + " | "
+      + " | ".join(f"{k} " + " ".join(f"{v:.2f}" for v in parts(st_)) for k, st_ in steps.items()), flush=True)
 print("steps/s: " + "  ".join(f"{k} {v:.2f}" for k, v in res.items()), flush=True)
 alive = {k: res[k] for k in steps}
 fast, slow = max(alive, key=alive.get), min(alive, key=alive.get)

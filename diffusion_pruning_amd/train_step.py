@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from . import dist_utils
 from . import autograd as AG
-from .graph_utils import new_graph, node_count
+from .graph_utils import concurrent_stream, new_graph, node_count
 from . import ops
 from .dist_utils import _rank, _span, _world
 from .losses import ContrastiveLoss, ResourceLoss, compute_snr
@@ -464,6 +464,7 @@ class GraphedPrunerStep(PrunerStep):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._cap = None
+        self.stream_probe = []          # what graph_utils.concurrent_stream measured when it chose the teacher's side stream
 
     # ---- capture ------------------------------------------------------------------------------------------------
     def _snr_weights(self, timesteps):
@@ -601,7 +602,7 @@ class GraphedPrunerStep(PrunerStep):
             ops.LAUNCH_LOG = user_log
         # (everything a captured kernel reads must outlive the graphs: `inv` is an operand of the gather that ends g_student_bwd)
         self._cap = dict(st=st, ga=ga, install_code=install_code, perm=perm, inv=inv, full=full, pred=pred, acts=acts, teacher_acts=teacher_acts, gw=gw, gd=gd, g_teacher=g_teacher, g_student=g_student, g_student_bwd=g_student_bwd,
-                         loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=torch.cuda.Stream(), vmacs=vmacs,
+                         loss=loss, dist=dist, blk=blk, grad=grad, full_pred=full_pred, side=concurrent_stream(log=self.stream_probe), vmacs=vmacs,
                          launch_log=launch_log, router=None)
         if optimizer is not None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self._capture_router(batch, optimizer, pretrain)       # (`dist` is the distillation loss in this scope)
@@ -936,6 +937,7 @@ class GraphedFineTunerStep(FineTunerStep):
         self.opt_kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
         self.optimizer = None
         self._cap = None
+        self.stream_probe = []          # what graph_utils.concurrent_stream measured when it chose the teacher's side stream
 
     def _losses(self, model_pred, full_pred, w, target):
         cfg = self.cfg
@@ -1083,7 +1085,7 @@ class GraphedFineTunerStep(FineTunerStep):
         self.optimizer = PackedAdamW(self.trainer, lr=self.opt_kw["lr"], betas=self.opt_kw["betas"], eps=self.opt_kw["eps"],
                                      weight_decay=self.opt_kw["weight_decay"], group_of=group_of)
         self._cap = dict(st=st, graph=graph, g_bwd=g_bwd, g_teacher=g_teacher, full_pred=full_pred, teacher_acts=teacher_acts,
-                         pred=pred, student_acts=student_acts, side=torch.cuda.Stream(),
+                         pred=pred, student_acts=student_acts, side=concurrent_stream(log=self.stream_probe),
                          tail_stream=torch.cuda.Stream(), ev_bwd=torch.cuda.Event(), ev_tail=None, launch_log=launch_log, **out)
         self.trainer.sync = self.finish          # (export_ / state_dict read the parameters: after the pending optimizer tail)
         return self

@@ -203,6 +203,39 @@ steps = {"B": B, "C": C, "D": D}
 print("per-graph ms (teacher, student fwd, student bwd), replayed alone: A " + " ".join(f"{v:.2f}" for v in pA) + " | "
       + " | ".join(f"{k} " + " ".join(f"{v:.2f}" for v in parts(st_)) for k, st_ in steps.items()), flush=True)
 print("steps/s: " + "  ".join(f"{k} {v:.2f}" for k, v in res.items()), flush=True)
+# the same captured graphs (B's) with OTHER side streams for the teacher: is it the stream the runtime handed out?
+from diffusion_pruning_amd.graph_utils import concurrent_stream  # noqa: E402
+orig = B._cap["side"]
+rows = []
+for k in range(10):
+    s_ = torch.cuda.Stream()
+    probe = []
+    # overlap probe of THIS stream against the launching stream: two spin kernels, ratio to one
+    cyc = int(0.4e-3 * 2.0e9)
+
+    def t_(side):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(cyc)
+        torch.cuda._sleep(cyc)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    t_(None); one = min(t_(None), t_(None)); t_(s_); two = min(t_(s_), t_(s_))
+    B._cap["side"] = s_
+    rows.append((k, two / one, max(measure(B), measure(B))))
+B._cap["side"] = orig
+print("capture B replayed with ten other side streams (spin-kernel overlap ratio: 1.0 = concurrent, 2.0 = serialised; steps/s):", flush=True)
+print("   " + "  ".join(f"#{k}: {r:.2f} / {v:.2f}" for k, r, v in rows), flush=True)
+chosen = concurrent_stream(log=(plog := []))
+C._cap["side"] = chosen
+print(f"capture C (the slow one) with a side stream chosen by graph_utils.concurrent_stream {plog}: {max(measure(C), measure(C)):.2f} steps/s (was {res['C']:.2f})", flush=True)
 alive = {k: res[k] for k in steps}
 fast, slow = max(alive, key=alive.get), min(alive, key=alive.get)
 print(f"fastest alive capture {fast} ({alive[fast]:.2f}), slowest {slow} ({alive[slow]:.2f}): {100 * (alive[fast] / alive[slow] - 1):.1f} % apart", flush=True)

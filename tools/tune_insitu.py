@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--wide", type=int, default=0, help="also shortlist the N fastest (isolated, warm) of ALL (tile, split-K, order) "
                     "combinations per shape and evaluate those in situ")
     ap.add_argument("--apply", action="store_true", help="also write the merged table over the package's own (for chained runs in one job)")
+    ap.add_argument("--batch", type=int, default=4, help="U-Net batch of the forward being tuned (16 = the reference's evaluation batch)")
     ap.add_argument("--lean", action="store_true", help="round 4: visit only the plain linear layers (1x1, stride 1) and try every tile the lean "
                     "kernel of csrc/lin_gemm.hip instantiates (one K-slice), in both XCD orders for the best one")
     args = ap.parse_args()
@@ -54,7 +55,7 @@ def main():
         model = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
         st = model.get_structure()
         model.set_structure(fixed_half_mask(st, dev))
-    B = 4
+    B = args.batch
     g = torch.Generator().manual_seed(1234)
     sample = torch.randn(B, 4, 64, 64, generator=g).to(dev)
     ehs = torch.randn(B, 77, 1024, generator=g).to(dev)
@@ -218,7 +219,12 @@ def main():
         nK = (K + 63) // 64
         cur = ops.tuning_lookup(*[int(v) if v else 0 for v in KEY.match(key).groups()[:7]], int(KEY.match(key).group(8) or 0))
         if cur is None:
-            continue
+            # no table entry and no neighbour: the launch took ops.conv_gemm's own choice (lean tile by row count, stream-K macro-tile,
+            # library heuristic) -- that is the incumbent
+            q0 = shapes[key]["params"]
+            if q0.tile == 0:
+                continue
+            cur = {"tile": int(q0.tile), "split_k": int(q0.split_k), "order": int(q0.order) if q0.order else 1, "in_kernel": int(bool(q0.tile_counters))}
         inc = (cur["tile"], cur["split_k"], cur.get("order", 1), int(cur.get("in_kernel", 0)))
         cands = set(by_class.get(c, ()))
         for dk in (-2, -1, 1, 2):                           # neighbours of the incumbent
@@ -229,6 +235,12 @@ def main():
             cands.add((inc[0], inc[1], o, inc[3]))
         if args.wide:
             cands.update(wide_shortlist(key, nK, args.wide))
+        if args.batch != 4:
+            T_ = int(KEY.match(key).group(4))
+            if T_ == 1:
+                cands.update({(t_, 1, inc[2], 0) for t_ in (11, 17, 12, 18, 49, 9, 15)})
+            else:
+                cands.update({(t_, sk_, 3, 1 if sk_ > 1 else 0) for t_ in (64, 65, 67, 19, 34, 56, 20) for sk_ in (1, 2)})
         if args.lean:
             cands = {(t_, 1, inc[2], 0) for t_ in LEAN_TILES}
             cands.update({(t_, 1, 5 - inc[2] if inc[2] in (2, 3) else 3, 0) for t_ in (12, 18, 49, 9, 11)})
@@ -271,6 +283,8 @@ def main():
     table = json.load(open(src)) if os.path.exists(src) else {}
     table.update(changed)
     tag = "dense" if args.dense else ("expert%d" % args.expert if args.expert is not None else "masked")
+    if args.batch != 4:
+        tag += "_bs%d" % args.batch
     json.dump(table, open(os.path.join(ROOT, "gpurun_out", "tuning_gfx950.json"), "w"), indent=0, sort_keys=True)
     if args.apply:
         json.dump(table, open(src, "w"), indent=0, sort_keys=True)

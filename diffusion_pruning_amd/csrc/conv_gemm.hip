@@ -1117,9 +1117,10 @@ const TileCfg kTiles[] = {
     {128, 160, 2, 8}, {128, 128, 4, 8},                                  // 49-57: two K-tiles per barrier
     {64, 64, 2, 4}, {64, 64, 2, 4}, {64, 128, 2, 4}, {64, 128, 2, 4}, {128, 64, 2, 4}, {128, 128, 2, 4},   // 58-63: intra-workgroup K split (compute grid 2 x 2)
     {256, 160, 2, 8}, {256, 128, 2, 8}, {128, 256, 4, 8},               // 64-66: persistent stream-K macro-tiles (conv_gemm_sk.hip)
-    {256, 160, 2, 8}, {256, 128, 2, 8}, {128, 256, 4, 8}};              // 67-69: the same, fragment reads in the load slot
-constexpr int kNumTiles = 70;
-inline bool is_sk_tile(int t) { return t >= APTP_TILE_SK_256x160 && t <= APTP_TILE_SKL_128x256; }
+    {256, 160, 2, 8}, {256, 128, 2, 8}, {128, 256, 4, 8},               // 67-69: the same, fragment reads in the load slot
+    {128, 160, 2, 8}, {128, 160, 2, 8}, {128, 128, 2, 8}, {128, 128, 2, 8}};   // 70-73: stream-K on 128-row tiles (round 4)
+constexpr int kNumTiles = 74;
+inline bool is_sk_tile(int t) { return t >= APTP_TILE_SK_256x160 && t <= APTP_TILE_SKL_128x128; }
 static_assert(sizeof(kTiles) / sizeof(kTiles[0]) == kNumTiles, "tile table");
 
 int pick_tile(const AptpConvGemmParams* p, int M) {
@@ -1465,7 +1466,8 @@ extern "C" int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream)
     case APTP_TILE_KS2S3_128x64: launch_tile_ks2<128, 64, 3>(k, s); break;
     case APTP_TILE_KS2S3_128x128: launch_tile_ks2<128, 128, 3>(k, s); break;
     case APTP_TILE_SK_256x160: case APTP_TILE_SK_256x128: case APTP_TILE_SK_128x256:
-    case APTP_TILE_SKL_256x160: case APTP_TILE_SKL_256x128: case APTP_TILE_SKL_128x256: {
+    case APTP_TILE_SKL_256x160: case APTP_TILE_SKL_256x128: case APTP_TILE_SKL_128x256:
+    case APTP_TILE_SK_128x160: case APTP_TILE_SKL_128x160: case APTP_TILE_SK_128x128: case APTP_TILE_SKL_128x128: {
       if (k.split_k > 1 && !k.counters) { aptp_set_error("conv_gemm: the stream-K tiles combine in-kernel: split_k > 1 needs tile_counters"); return APTP_EINVAL; }
       const int rc2 = aptp_launch_sk(k, t, s);
       if (rc2 != APTP_OK) return rc2;

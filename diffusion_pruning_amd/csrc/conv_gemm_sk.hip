@@ -432,6 +432,10 @@ int aptp_launch_sk(const KParams& k, int tile, hipStream_t s) {
     case APTP_TILE_SKL_256x160: return launch_sk<256, 160, 4, 2, false>(k, s);
     case APTP_TILE_SKL_256x128: return launch_sk<256, 128, 4, 2, false>(k, s);
     case APTP_TILE_SKL_128x256: return launch_sk<128, 256, 2, 4, false>(k, s);
+    case APTP_TILE_SK_128x160: return launch_sk<128, 160, 4, 2, true>(k, s);
+    case APTP_TILE_SKL_128x160: return launch_sk<128, 160, 4, 2, false>(k, s);
+    case APTP_TILE_SK_128x128: return launch_sk<128, 128, 4, 2, true>(k, s);
+    case APTP_TILE_SKL_128x128: return launch_sk<128, 128, 4, 2, false>(k, s);
     default: aptp_set_error("conv_gemm: unknown stream-K tile %d", tile); return APTP_EINVAL;
   }
 }

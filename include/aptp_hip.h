@@ -192,7 +192,11 @@ enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TI
        APTP_TILE_SK_256x160 = 64, APTP_TILE_SK_256x128 = 65, APTP_TILE_SK_128x256 = 66,
        /* the same with a phase's fragment reads in its own load slot (beside the OTHER group's MFMAs) instead of one phase
         * ahead beside the wave's own MFMAs: one register set, shorter DMA lead (tuner candidates) */
-       APTP_TILE_SKL_256x160 = 67, APTP_TILE_SKL_256x128 = 68, APTP_TILE_SKL_128x256 = 69 };
+       APTP_TILE_SKL_256x160 = 67, APTP_TILE_SKL_256x128 = 68, APTP_TILE_SKL_128x256 = 69,
+       /* round 4: the same persistent stream-K kernels on 128-row tiles -- the tile sizes the batch-4 launches fill the chip with
+        * (128 tiles of 128 x 160 at level 64 = one two-way split per tile, like the ping-pong tile's own split-K), with the
+        * macro-tile kernel's per-lane offset tables and two-slot schedule instead of the per-step tap logic */
+       APTP_TILE_SK_128x160 = 70, APTP_TILE_SKL_128x160 = 71, APTP_TILE_SK_128x128 = 72, APTP_TILE_SKL_128x128 = 73 };
 
 int aptp_conv_gemm(const AptpConvGemmParams* p, aptp_stream_t stream);
 int64_t aptp_conv_gemm_workspace_bytes(const AptpConvGemmParams* p);

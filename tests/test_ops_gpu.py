@@ -403,7 +403,8 @@ def test_splitk_in_kernel_matches_reduce_launch_bitwise_and_is_stable(ops, cuda,
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout,k,tile", [(4, 16, 2560, 1280, 1, 64), (4, 8, 1280, 640, 3, 65), (4, 32, 320, 640, 3, 64),
-                                                 (1, 24, 64, 200, 3, 66), (4, 16, 640, 1280, 3, 66)])
+                                                 (1, 24, 64, 200, 3, 66), (4, 16, 640, 1280, 3, 66),
+                                                 (4, 32, 320, 160, 3, 70), (4, 16, 640, 1280, 3, 71), (1, 24, 64, 200, 3, 72), (4, 32, 640, 320, 3, 73)])
 def test_streamk_is_stable_and_close_to_whole_tiles(ops, cuda, B, H, Cin, Cout, k, tile):
     """The persistent stream-K tiles: a partial tile's ranges are summed in range order by whichever workgroup arrives last,
     so many back-to-back launches -- interleaved with stream-K launches of another geometry on the same counters -- must be

@@ -73,7 +73,11 @@ def time_graph(fn, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--tiles128", action="store_true", help="round 4: the 128-row stream-K tiles (70-73) on the convolution shapes only")
     args = ap.parse_args()
+    global CONFIGS
+    if args.tiles128:
+        CONFIGS = [(t, s_, o) for t in (70, 71, 72, 73) for (s_, o) in ((1, 3), (2, 3), (2, 2))]
     ops._lib.load()
     ops._tile_counters(dev)
     lines = []
@@ -83,7 +87,7 @@ def main():
         lines.append(s)
 
     gen = torch.Generator().manual_seed(0)
-    shapes = SHAPES[:6] if args.quick else SHAPES
+    shapes = SHAPES[:6] if args.quick else (SHAPES[:17] if args.tiles128 else SHAPES)
     for (B, H, W, Cin, N, k, ups, Cin2, geglu) in shapes:
         x = torch.randn(B, H, W, Cin, generator=gen).bfloat16().to(dev)
         w = torch.randn(N, Cin, k, k, generator=gen) / (Cin * k * k) ** 0.5
@@ -118,7 +122,7 @@ def main():
                         best = (us, tile, sk, order)
         out(f"  best SK {best}  speed-up {base / best[0]:.2f}x")
     # plain GEMM
-    for n in ((4096, 8192) if not args.quick else (8192,)):
+    for n in (() if args.tiles128 else ((4096, 8192) if not args.quick else (8192,))):
         a = torch.randn(n, n, generator=gen).bfloat16().to(dev)
         bt = torch.randn(n, n, generator=gen).bfloat16()
         pw = ops.pack_weight(bt.float(), None, device=dev)
@@ -134,7 +138,7 @@ def main():
                     us = time_graph(lambda: ops.conv_gemm(xx, pw, pad=0, tile=tile, split_k=sk, order=order), reps=3)
                     out(f"    t{tile} s{sk} o{order}: {fl / us / 1e6:7.1f} TF")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "bench_sk.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "bench_sk128.txt" if args.tiles128 else "bench_sk.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
 
 

@@ -11,7 +11,9 @@ import json
 import os
 import sys
 
-LAUNCHES_PER_STEP = 174      # launches of the family in one headline forward: 169 aptp_conv_gemm + 5 aptp_ff_tail (bench.py: roofline.launches_per_step)
+# launches of the family in one headline forward (bench.py: roofline.launches_per_step): 184 aptp_conv_gemm since round 4 (the fused
+# tail is off by default; rounds 2-3: 169 + 5 aptp_ff_tail = 174); overridable as the 4th argument
+LAUNCHES_PER_STEP = int(sys.argv[4]) if len(sys.argv) > 4 else 184
 
 
 def family_sum(d, counter):
@@ -24,9 +26,9 @@ def family_sum(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             name = r["Kernel_Name"]
-            if "conv_gemm" in name or "splitk_reduce" in name or "ff_tail" in name:
+            if "conv_gemm" in name or "lin_gemm" in name or "splitk_reduce" in name or "ff_tail" in name:
                 total += float(r["Counter_Value"])
-                if "conv_gemm" in name or "ff_tail" in name:
+                if "conv_gemm" in name or "lin_gemm" in name or "ff_tail" in name:
                     key = (r.get("Dispatch_Id"), f)
                     if key not in seen:
                         seen.add(key)
@@ -44,7 +46,7 @@ def main():
     hbm = (2.0 * fetch_per_step + write_per_step) * 1024.0
     res = {
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph",
-        "kernel_family": "conv_gemm_kernel / conv_gemm_dma_kernel / ff_tail_kernel (+ splitk_reduce_kernel)",
+        "kernel_family": "conv_gemm_kernel / conv_gemm_dma_kernel / lin_gemm_kernel / ff_tail_kernel (+ splitk_reduce_kernel)",
         "forwards_profiled": steps_f,
         "FETCH_SIZE_KB_per_step_raw": fetch_per_step,
         "WRITE_SIZE_KB_per_step": write_per_step,

@@ -359,3 +359,20 @@ def test_captured_router_trains_like_the_eager_router(cuda):
             assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-5, (k, a, b)
     assert float((pa - p0).abs().max()) > 0
     assert rel_l2(pb - p0, pa - p0) <= 2e-2, rel_l2(pb - p0, pa - p0)
+
+
+def test_side_stream_is_chosen_by_an_overlap_probe(cuda):
+    """graph_utils.concurrent_stream: the side stream of the graphed steps must really run next to the launching stream (every
+    fourth stream torch hands out shares the launching stream's hardware queue and serialises behind it -- the mechanism of
+    rounds 2-3's "capture-order variance", profiles/r4_capture_variance_hw_queues.txt).  Requested many times in a row -- i.e.
+    from every position of torch's stream pool -- it always returns a stream whose spin kernel overlaps the main stream's."""
+    from diffusion_pruning_amd.graph_utils import concurrent_stream
+    ratios, tried = [], 0
+    for _ in range(9):
+        log = []
+        s = concurrent_stream(log=log)
+        assert isinstance(s, torch.cuda.Stream)
+        ratios.append(log[0]["chosen_ratio"])
+        tried += len(log[0]["ratios_tried"])
+    assert max(ratios) < 1.5, ratios          # 1.07 when concurrent, 2.07 when serialised
+    assert tried >= 9

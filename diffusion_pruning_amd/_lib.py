@@ -51,11 +51,13 @@ class ConvGemmParams(Structure):
         ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_groups", c_int32), ("gn_C", c_int32), ("gn_silu", c_int32),
         ("gn_eps", c_float),
         ("io_f32", c_int32),
+        ("ustat_out", c_void_p), ("ustat_unit", c_int32), ("ustat_units", c_int32), ("ustat_nrep", c_int32),
     ]
 
 
 class GroupNormColStats(Structure):
-    _fields_ = [("stats", c_void_p), ("ld", c_int32), ("rows_per_block", c_int32), ("C", c_int32)]
+    _fields_ = [("stats", c_void_p), ("ld", c_int32), ("rows_per_block", c_int32), ("C", c_int32),
+                ("ustats", c_void_p), ("unit", c_int32), ("units", c_int32), ("nrep", c_int32)]
 
 
 class GroupNormParams(Structure):

@@ -1217,6 +1217,10 @@ int fill_kparams(const AptpConvGemmParams* p, KParams& k) {
   k.pf_ptr = ((uintptr_t)p->prefetch & 3) ? nullptr : (const char*)p->prefetch;   // dword loads
   k.pf_bytes = k.pf_ptr ? (p->prefetch_bytes < (1ll << 36) ? p->prefetch_bytes : (1ll << 36)) : 0;   // (line index fits an int)
   k.cstat_out = p->colstat_out; k.cstat_ld = p->colstat_ld;
+  k.ustat_out = (long long*)p->ustat_out; k.ustat_unit = p->ustat_unit; k.ustat_units = p->ustat_units; k.ustat_nrep = p->ustat_nrep;
+  APTP_CHECK(!p->ustat_out || (p->colstat_out && p->ustat_unit > 0 && p->ustat_units * p->ustat_unit >= nout && p->ustat_nrep >= 1 &&
+                               (p->ustat_nrep & (p->ustat_nrep - 1)) == 0 && ((uintptr_t)p->ustat_out % 8) == 0),
+             "conv_gemm: ustat_out goes with colstat_out; ustat_unit > 0, ustat_units >= ceil(N_out / unit), ustat_nrep a power of two");
   k.epi16 = !p->out_f32 && p->ldy % 8 == 0 && ((uintptr_t)p->y % 16) == 0 && nout % 8 == 0 &&
             (!p->residual || (p->ldres % 8 == 0 && ((uintptr_t)p->residual % 16) == 0)) &&
             (!p->depth || (p->lddin % 8 == 0 && ((uintptr_t)p->depth_in % 16) == 0));

@@ -72,6 +72,7 @@ struct KParams {
   float* rstat_out; int rstat_slots;                       // per-row (sum, sumsq) partials of the stored outputs
   const float* ln_stats; int ln_slots; const float* ln_colsum; float ln_eps; float ln_invC;   // folded LayerNorm
   const float* gn_gamma; const float* gn_beta; int gn_groups, gn_C, gn_silu; float gn_eps;   // reduce launch applies a GroupNorm
+  long long* ustat_out; int ustat_unit, ustat_units, ustat_nrep;   // per-(sample, channel unit) fixed-point statistics (atomics)
   FastDiv fd_hw, fd_wout;                    // / HW, / Wout (per lane)
   FastDiv fd_tm, fd_tn, fd_sk, fd_perm, fd_tmn;   // decode_block: / tiles_m, / tiles_n, / split_k, / (tiles_n * split_k), / (tiles_m * tiles_n)
 };
@@ -405,6 +406,41 @@ __device__ __forceinline__ void tile_epilogue(const KParams& p, f32x4 (&acc)[MF]
   }
 }
 
+// Unit statistics (AptpConvGemmParams.ustat_out): a wave that has the per-channel (sum, sumsq) of its WTM x WL block in `tot`
+// (lane t + 64 q <-> channel cw0 + t + 64 q) stages them in its LDS slice, then lane u folds the channels of the u-th unit its
+// columns touch and adds the two sums to the (replica, sample, unit) slot as 64-bit fixed point.  Integer addition is
+// associative: the totals are independent of arrival order, i.e. deterministic, unlike float atomics.
+constexpr float USTAT_SUM_SCALE = 1048576.0f;     // 2^20
+constexpr float USTAT_SQ_SCALE = 4096.0f;         // 2^12
+template <int WL>
+__device__ __forceinline__ void emit_unit_stats(const KParams& p, const float (&tot)[2][(WL + 63) / 64], float* buf, int lane, int cw0,
+                                                int row0) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < (WL + 63) / 64; ++q) {
+    const int t = lane + 64 * q;
+    if (t < WL) { buf[t] = tot[0][q]; buf[WL + t] = tot[1][q]; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int cend = cw0 + WL < p.Nout ? cw0 + WL : p.Nout;
+  if (cw0 >= cend || row0 >= p.M) return;
+  const int unit = p.ustat_unit;
+  const int u0 = cw0 / unit, u1 = (cend - 1) / unit;
+  const int u = u0 + lane;
+  if (u > u1) return;
+  const int lo = (u * unit > cw0 ? u * unit : cw0) - cw0;
+  const int hi = ((u + 1) * unit < cend ? (u + 1) * unit : cend) - cw0;
+  float s = 0.f, s2 = 0.f;
+  for (int c = lo; c < hi; ++c) { s += buf[c]; s2 += buf[WL + c]; }
+  const int b = p.fd_hw.div(row0);
+  const int rep = (int)blockIdx.x & (p.ustat_nrep - 1);
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.ustat_out) + (((int64_t)rep * p.B + b) * p.ustat_units + u) * 2;
+  __hip_atomic_fetch_add(dst, (unsigned long long)__float2ll_rn(s * USTAT_SUM_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(dst + 1, (unsigned long long)__float2ll_rn(s2 * USTAT_SQ_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Coalesced epilogue (bf16 outputs whose rows are 16-byte aligned).  The MFMA accumulator layout gives a lane 4 columns
 // of 16 different rows, so storing from it costs one 8-byte access per (row, quad): 16 x 32-byte pieces per wave
 // instruction, and as many again for the residual / depth-gate operands.  The short-K launches of the masked U-Net
@@ -594,6 +630,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const KParams& p, f32x4 (&acc)
         const int t = lane + 64 * q;
         if (t < WL && cw0 + t < p.Nout) dstg[cw0 + t] = make_float2(tot[0][q], tot[1][q]);
       }
+      if (p.ustat_out) emit_unit_stats<WL>(p, tot, buf, lane, cw0, m0 + wm * WTM);
     }
   }
 }

@@ -391,6 +391,9 @@ __global__ __launch_bounds__(WM * WN * 64) void lin_gemm_kernel(const KParams p)
       const int t = lane + 64 * q;
       if (t < WTN && cw0 + t < p.Nout) dstg[cw0 + t] = make_float2(tot[0][q], tot[1][q]);
     }
+    if constexpr (!GEGLU) {
+      if (p.ustat_out) emit_unit_stats<WTN>(p, tot, buf, lane, cw0, m0 + wm * WTM);
+    }
   }
 }
 

@@ -23,6 +23,9 @@ struct GnK {
   int* counters;             // optional [B] arrival counters (zero on entry, left zero): the last stage-1 workgroup of a
                              // sample folds the partials itself and gn_finalize_kernel is not launched
   int TPR, RPAR;             // threads per row (= min(CO,256)), rows processed in parallel (256/TPR)
+  // round 4: per-(sample, channel unit) fixed-point sums left by the producer(s) (AptpGroupNormColStats.ustats): the apply pass
+  // finishes (mean, rstd) itself -- no finalise launch.  Up to two channel segments (skip-concat).
+  const long long* us[2]; int us_units[2]; int us_segC0; int us_unit, us_nrep;
 };
 
 // stage 1.5: one workgroup per sample folds the nchunk partials ONCE (fixed order => deterministic).  Without it every
@@ -272,6 +275,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
     }
   };
   load_rows(r0 + rl);
+  if (p.us[0]) {
+    // 8 threads per group: each takes every 8th (unit, replica) pair of its group, 64-bit integer sums (order-independent),
+    // folded over the 8 lanes; then mean / rstd in double (the fixed-point totals carry ~40 significant bits)
+    const int g = tid >> 3, sub = tid & 7;
+    long long S = 0, S2 = 0;
+    if (g < p.G) {
+      const int upg = p.cg / p.us_unit, u_lo = g * upg, useg0 = p.us_segC0 / p.us_unit;
+      const int n = upg * p.us_nrep;
+      for (int i = sub; i < n; i += 8) {
+        const int u = u_lo + i / p.us_nrep, r = i % p.us_nrep;
+        const int sg = u < useg0 ? 0 : 1, lu = sg ? u - useg0 : u;
+        const long long* q = p.us[sg] + (((int64_t)r * p.B + b) * p.us_units[sg] + lu) * 2;
+        S += q[0]; S2 += q[1];
+      }
+    }
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) { S += __shfl_xor(S, off); S2 += __shfl_xor(S2, off); }
+    if (g < p.G && sub == 0) {
+      const double inv = 1.0 / ((double)p.cg * (double)p.HW);
+      const double mean = (double)S * (1.0 / 1048576.0) * inv;
+      double var = (double)S2 * (1.0 / 4096.0) * inv - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      mean_s[g] = (float)mean;
+      rstd_s[g] = rsqrtf((float)var + p.eps);
+    }
+  } else
   if (tid < p.G) {
     if (p.fold_in_apply) {
       // two-launch form: at most 16 coarse chunks, all requested at once (one L2 round trip, in flight together with the
@@ -668,7 +697,26 @@ extern "C" int aptp_groupnorm(const AptpGroupNormParams* p, aptp_stream_t stream
   }
   dim3 grid1(k.nchunk, p->B);
   const bool from_cols = p->colstats[0].stats != nullptr;
-  if (from_cols) {
+  k.us[0] = k.us[1] = nullptr; k.us_units[0] = k.us_units[1] = 0; k.us_segC0 = 0; k.us_unit = 1; k.us_nrep = 1;
+  bool from_units = from_cols && p->colstats[0].ustats != nullptr;
+  if (from_units) {
+    // unit statistics: every segment must have them, with one unit size / replica count that divides the group size and the segments
+    const int unit = p->colstats[0].unit, nrep = p->colstats[0].nrep;
+    int ctot = 0;
+    for (int i = 0; i < 2 && from_units; ++i) {
+      const AptpGroupNormColStats& d = p->colstats[i];
+      if (!d.stats) continue;
+      from_units = d.ustats && d.unit == unit && d.nrep == nrep && unit > 0 && nrep >= 1 && d.C % unit == 0 && d.units * unit >= d.C &&
+                   ((uintptr_t)d.ustats % 8) == 0;
+      ctot += d.C;
+    }
+    from_units = from_units && ctot == p->C && (p->C / p->groups) % unit == 0;
+    if (from_units) {
+      for (int i = 0; i < 2; ++i) { k.us[i] = (const long long*)p->colstats[i].ustats; k.us_units[i] = p->colstats[i].units; }
+      k.us_segC0 = p->colstats[0].C; k.us_unit = unit; k.us_nrep = nrep;
+    }
+  }
+  if (from_cols && !from_units) {
     GnCols c;
     int ctot = 0;
     for (int i = 0; i < 2; ++i) {

@@ -395,19 +395,70 @@ def _root(t: torch.Tensor) -> torch.Tensor:
     return t._base if t._base is not None else t
 
 
+# Round 4: GroupNorm statistics WITHOUT a finalise launch.  A producer that emits column statistics also adds per-(sample, channel
+# unit) fixed-point sums to a slice of a zeroed arena (AptpConvGemmParams.ustat_out: 64-bit integer atomics, order-independent);
+# when every producer of a GroupNorm's input left them, the apply pass finishes mean / rstd itself (AptpGroupNormColStats.ustats).
+# The arena belongs to ONE forward: the model calls ustat_begin() at the top of its forward (that zeroes it: one fill launch, also
+# inside a captured graph) and ustat_end() at the end; outside such a bracket nothing is emitted.  USTAT_UNIT = channels per unit:
+# it must divide every GroupNorm group size of the model (SD-2.1: 320 / 32 = 10); 0 = off.
+USTAT = os.environ.get("APTP_USTAT", "1") != "0"
+USTAT_NREP = int(os.environ.get("APTP_USTAT_NREP", "8"))
+_USTAT_WORDS = 1 << 19            # int64 words per arena (4 MiB): ~60 producers x 8 replicas x 4 samples x 128 units x 2
+_ustat_arenas = {}
+
+
+def ustat_begin(device, unit: int):
+    """open the unit-statistics arena of the forward that starts now on the current stream (zeroed here); unit <= 0 or
+    APTP_USTAT=0: no arena, producers emit column statistics only"""
+    if not USTAT or unit <= 0 or torch.device(device).type != "cuda":
+        _tls.ustat = None
+        return
+    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream, _domain())
+    buf = _ustat_arenas.get(key)
+    if buf is None:
+        buf = torch.zeros(_USTAT_WORDS, dtype=torch.int64, device=device)
+        _ustat_arenas[key] = buf
+        if torch.cuda.is_current_stream_capturing():
+            _ws_capture_keep.append(buf)
+    st = getattr(_tls, "ustat", None)
+    used = st["off"] if (st is not None and st["buf"] is buf) else _USTAT_WORDS
+    buf[:max(used, 2)].zero_()          # what the previous forward on this arena used (the whole arena the first time)
+    _tls.ustat = {"buf": buf, "off": 0, "unit": int(unit), "last": used}
+
+
+def ustat_end():
+    st = getattr(_tls, "ustat", None)
+    if st is not None:
+        st["closed"] = True
+
+
+def _ustat_alloc(B: int, nout: int):
+    st = getattr(_tls, "ustat", None)
+    if st is None or st.get("closed"):
+        return None
+    unit = st["unit"]
+    units = (nout + unit - 1) // unit
+    n = USTAT_NREP * B * units * 2
+    if st["off"] + n > st["buf"].numel():
+        return None
+    u = st["buf"][st["off"]:st["off"] + n]
+    st["off"] += n
+    return u, unit, units, USTAT_NREP
+
+
 def _colstats_drop(out: torch.Tensor):
     d = getattr(_root(out), "_aptp_colstats", None)
     if d:
         d.pop(out.storage_offset(), None)
 
 
-def _colstats_put(out: torch.Tensor, stats: torch.Tensor, rows_per_block: int):
+def _colstats_put(out: torch.Tensor, stats: torch.Tensor, rows_per_block: int, ustat=None):
     root = _root(out)
     d = getattr(root, "_aptp_colstats", None)
     if d is None:
         d = {}
         root._aptp_colstats = d
-    d[out.storage_offset()] = (stats, rows_per_block, out.shape[3], (out.shape[0], out.shape[1] * out.shape[2]), _ld(out))
+    d[out.storage_offset()] = (stats, rows_per_block, out.shape[3], (out.shape[0], out.shape[1] * out.shape[2]), _ld(out), ustat)
 
 
 def _colstats_get(x: torch.Tensor, C: int):
@@ -421,7 +472,7 @@ def _colstats_get(x: torch.Tensor, C: int):
         rec = d.get(off)
         if rec is None or rec[3] != (x.shape[0], x.shape[1] * x.shape[2]) or rec[4] != _ld(x) or rec[2] > left:
             return None
-        segs.append([rec[0], rec[1], rec[2]])
+        segs.append([rec[0], rec[1], rec[2], rec[5] if len(rec) > 5 else None])
         off += rec[2]
         left -= rec[2]
     if left != 0 or segs[-1][2] <= pad:
@@ -665,7 +716,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         assert slots % 2 == 0
         stats = torch.empty(slots // 2, B * Hout * Wout, 4, dtype=torch.float32, device=x.device)
         p.rowstat_out, p.rowstat_slots = stats.data_ptr(), slots
-    cstats = None
+    cstats = ustat = None
     if colstats and COLSTATS and Hout * Wout >= COLSTATS_MIN_HW and act != ACT_GEGLU and not out_f32 \
             and (p.split_k == 1 or cnt is not None) and _ld(out) % 8 == 0 and out.data_ptr() % 16 == 0 and nout % 8 == 0 \
             and (residual is None or (_ld(residual) % 8 == 0 and residual.data_ptr() % 16 == 0)) \
@@ -676,6 +727,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             nblk = (M + rpb - 1) // rpb + 16          # (+ the padding blocks of the last, partial tile)
             cstats = torch.empty(nblk, nout, 2, dtype=torch.float32, device=x.device)
             p.colstat_out, p.colstat_ld = cstats.data_ptr(), nout
+            ustat = _ustat_alloc(B, nout)
+            if ustat is not None:
+                p.ustat_out, p.ustat_unit, p.ustat_units, p.ustat_nrep = ustat[0].data_ptr(), ustat[1], ustat[2], ustat[3]
     if ln is not None:
         ln_stats, ln_eps = ln
         if pw.ln_colsum is None:
@@ -688,10 +742,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         raise ValueError("conv_gemm: weights with a folded LayerNorm need ln=(stats, eps)")
     _lib.check(lib.aptp_conv_gemm(ctypes.byref(p), _stream()), "aptp_conv_gemm")
     if cstats is not None:
-        _colstats_put(out, cstats, rpb)
+        _colstats_put(out, cstats, rpb, ustat)
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append({"params": p, "flops": 2.0 * B * Hout * Wout * pw.N * (pw.KH * pw.KW * pw.Cin + pw.Cin2),
-                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats, x2, gn)})
+                           "keep": (x, pw, out, rowbias, colgate, corr, residual, depth, depth_in, ws, stats, ln, cnt, cstats, x2, gn, ustat)})
     if f32 and gn_f32 is not None:
         gn = gn_f32
     if gn is not None and not gn_fused:
@@ -752,8 +806,10 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
     p.workspace = ws.data_ptr()
     segs = _colstats_get(x, C) if (COLSTATS and variant == 0 and H * W >= COLSTATS_MIN_HW) else None
     if segs is not None:
-        for i, (st, rpb, cseg) in enumerate(segs):
+        for i, (st, rpb, cseg, us) in enumerate(segs):
             p.colstats[i].stats, p.colstats[i].ld, p.colstats[i].rows_per_block, p.colstats[i].C = st.data_ptr(), st.shape[1], rpb, cseg
+            if us is not None and us[0].shape[0] == USTAT_NREP * B * us[2] * 2:
+                p.colstats[i].ustats, p.colstats[i].unit, p.colstats[i].units, p.colstats[i].nrep = us[0].data_ptr(), us[1], us[2], us[3]
         p.variant = 1                       # the multi-launch skeleton (statistics pass replaced by the finalise)
     cnt = _tile_counters(x.device) if (GN_FUSED_FINALIZE and B <= _N_COUNTERS) else None
     if cnt is not None:

@@ -1727,10 +1727,23 @@ class UNet2DConditionModelGated(nn.Module):
         if mode not in plans:
             plans[mode] = ops._PrefetchPlan()
         ops.set_prefetch_plan(plans[mode])
+        if not mode and sample.is_cuda:
+            # GroupNorm statistics without finalise launches (ops.ustat_begin): channel unit = gcd of the levels' group sizes
+            # (SD-2.1: 320 / 32 = 10), which every group of every GroupNorm of this model -- skip-concats included -- is a multiple of
+            unit = self.__dict__.get("_ustat_unit")
+            if unit is None:
+                import math
+                g = self.conv_norm_out.num_groups
+                unit = 0
+                for c in self.config["block_out_channels"]:
+                    unit = math.gcd(unit, c // g) if c % g == 0 else 1
+                unit = self.__dict__["_ustat_unit"] = unit if unit >= 4 else 0
+            ops.ustat_begin(dev, unit)
         try:
             return self._forward_impl(sample, timestep, encoder_hidden_states, return_dict)
         finally:
             ops.set_prefetch_plan(None)
+            ops.ustat_end()
 
     def _forward_impl(self, sample, timestep, encoder_hidden_states, return_dict):
         dev = sample.device

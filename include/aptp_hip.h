@@ -148,6 +148,14 @@ typedef struct {
    * register-staged kernel (tiles 1..6 only).  Pins addressing and epilogue order on the GPU against the fp32 oracle at 1e-5
    * per op; the reference computes in fp32 (configs/pruning/sd-2-1_cc3m.yaml:79). */
   int32_t io_f32;
+  /* round 4, optional, together with colstat_out: GroupNorm statistics the consumer can use WITHOUT a finalise launch.  Every
+   * wave that emits column statistics also adds, per channel unit of `ustat_unit` consecutive output channels it touches, the
+   * (sum, sum of squares) of its stored values to ustat_out[rep][sample][unit][2] -- int64 fixed point (sum * 2^20, squares *
+   * 2^12), 64-bit integer atomics: the totals do not depend on the order of arrival (deterministic), `ustat_nrep` (a power of
+   * two) replicas selected by the workgroup index spread the contention.  The buffer must be ZERO on entry
+   * (nrep * B * ustat_units * 2 words, ustat_units = ceil(N_out / ustat_unit)); nobody resets it. */
+  void* ustat_out;
+  int32_t ustat_unit, ustat_units, ustat_nrep;
 } AptpConvGemmParams;
 
 enum { APTP_TILE_AUTO = 0, APTP_TILE_128x128 = 1, APTP_TILE_128x160 = 2, APTP_TILE_64x128 = 3, APTP_TILE_64x160 = 4,
@@ -224,6 +232,12 @@ int aptp_conv_gemm_suggest_split_k(const AptpConvGemmParams* p);
 typedef struct {
   const float* stats;       /* [B*HW/rows_per_block (+ padding blocks), ld, 2] or NULL */
   int32_t ld, rows_per_block, C;
+  /* round 4, optional: the same producer also left per-(sample, channel UNIT) sums (AptpConvGemmParams.ustat_out): int64
+   * fixed point [nrep][B][units][2] (sum * 2^20, sum of squares * 2^12), `unit` channels per unit.  When every segment has
+   * them, C of every segment and C / groups are multiples of `unit`, the apply pass finishes mean / rstd itself and NO
+   * finalise launch runs (one launch per GroupNorm). */
+  const void* ustats;
+  int32_t unit, units, nrep;
 } AptpGroupNormColStats;
 
 typedef struct {

@@ -1103,3 +1103,69 @@ def test_lean_geglu_projection_equals_the_general_kernel(ops, cuda, tile, M, C, 
     hg = pre @ w1f.t() + (b1 + w1 @ beta)
     ref = hg[:, :inner] * F.gelu(hg[:, inner:])
     assert rel_l2(y.float().reshape(M, -1)[:, :inner].cpu(), ref) <= REL_L2_TOL
+
+
+@pytest.mark.parametrize("tile", [0, 18, 11, 34, 19])
+@pytest.mark.parametrize("B,H,C0,C1,k,groups", [(4, 32, 320, 0, 1, 32), (2, 64, 160, 160, 3, 32), (4, 32, 640, 320, 3, 32), (2, 32, 170, 0, 3, 17)])
+def test_groupnorm_from_unit_statistics_needs_no_finalise_launch(ops, cuda, tile, B, H, C0, C1, k, groups):
+    """Round 4: a producer inside an ops.ustat_begin() bracket also leaves per-(sample, 10-channel unit) fixed-point sums (64-bit
+    integer atomics: AptpConvGemmParams.ustat_out); F.group_norm of its output (blocks.py:296-301,350-359) then runs as ONE launch.
+    One producer or two (skip-concat, blocks.py:485-495), lean and general kernels, compacted 17 x 10 channels: the unit sums
+    equal the sums of the stored bf16 values, the GroupNorm equals the finalise-launch form, and repeated runs are bit-identical
+    (integer accumulation does not depend on the order of arrival)."""
+    g = torch.Generator().manual_seed(B * H + C0 + C1 + k + tile)
+    unit = 10
+    Ctot = C0 + C1
+    cat = torch.empty(B, H, H, (Ctot + 7) // 8 * 8, dtype=torch.bfloat16, device=cuda)
+    cat.zero_()
+    segs = [(0, C0)] + ([(C0, C1)] if C1 else [])
+    xs, pws = [], []
+    for (off, Cn) in segs:
+        Cin = 128 if k == 1 else 64
+        xs.append(nhwc(_rand((B, Cin, H, H), g)).bfloat16().to(cuda))
+        pws.append(ops.pack_weight(_rand((Cn, Cin, k, k), g, 1.0 / math.sqrt(Cin * k * k)), _rand((Cn,), g, 0.3), device=cuda))
+    gamma, beta = (torch.rand(Ctot, generator=g) + 0.5).to(cuda), (_rand((Ctot,), g, 0.1)).to(cuda)
+
+    def produce(with_units):
+        if with_units:
+            ops.ustat_begin(cuda, unit)
+        try:
+            for (off, Cn), x, pw in zip(segs, xs, pws):
+                Cp = pw.N
+                ops.conv_gemm(x, pw, out=cat[..., off:off + Cp] if (off + Cp <= cat.shape[3]) else None, colstats=True, tile=tile)
+        finally:
+            ops.ustat_end()
+    if any(o + pw.N > cat.shape[3] or (o % 8) for (o, _), pw in zip(segs, pws)):
+        pytest.skip("segment layout not expressible as channel slices of one buffer")
+    produce(True)
+    rec = ops._colstats_get(cat, Ctot)
+    assert rec is not None and all(r[3] is not None for r in rec), "every producer must have left unit statistics"
+    # the unit sums themselves
+    yf = cat.float()
+    for (off, Cn), r in zip(segs, rec):
+        us, u_unit, units, nrep = r[3]
+        tot = us.view(nrep, B, units, 2).sum(0).double()
+        ref = yf[..., off:off + Cn].reshape(B, H * H, Cn)
+        nu = Cn // unit
+        rs = ref[..., :nu * unit].reshape(B, H * H, nu, unit).double()
+        assert torch.allclose(tot[:, :nu, 0] / 2 ** 20, rs.sum((1, 3)), rtol=1e-5, atol=2e-2)
+        assert torch.allclose(tot[:, :nu, 1] / 2 ** 12, (rs * rs).sum((1, 3)), rtol=1e-5, atol=5e-1)
+    ops.GN_LAUNCH_LOG = []
+    try:
+        y_units = ops.groupnorm(cat, gamma, beta, groups, 1e-5, True, C=Ctot)
+        used = ops.GN_LAUNCH_LOG[-1]["params"].colstats[0].ustats
+    finally:
+        ops.GN_LAUNCH_LOG = None
+    assert used, "the GroupNorm must have taken the unit statistics"
+    snapshot = [r[3][0].clone() for r in rec]
+    produce(False)                                   # same producers, column statistics only: the finalise-launch form
+    y_fin = ops.groupnorm(cat, gamma, beta, groups, 1e-5, True, C=Ctot)
+    ref = F.silu(F.group_norm(yf[..., :Ctot].permute(0, 3, 1, 2), groups, gamma.float(), beta.float(), 1e-5)).permute(0, 2, 3, 1)
+    assert rel_l2(y_units[..., :Ctot].float(), ref) <= REL_L2_TOL
+    assert rel_l2(y_units.float(), y_fin.float()) <= 2e-4
+    for _ in range(5):                               # deterministic: integer sums, whatever the arrival order
+        produce(True)
+        rec2 = ops._colstats_get(cat, Ctot)
+        for a, r in zip(snapshot, rec2):
+            assert torch.equal(a, r[3][0])
+        assert torch.equal(ops.groupnorm(cat, gamma, beta, groups, 1e-5, True, C=Ctot), y_units)

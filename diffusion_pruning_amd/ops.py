@@ -403,7 +403,7 @@ def _root(t: torch.Tensor) -> torch.Tensor:
 # it must divide every GroupNorm group size of the model (SD-2.1: 320 / 32 = 10); 0 = off.
 USTAT = os.environ.get("APTP_USTAT", "1") != "0"
 USTAT_NREP = int(os.environ.get("APTP_USTAT_NREP", "8"))
-_USTAT_WORDS = 1 << 19            # int64 words per arena (4 MiB): ~60 producers x 8 replicas x 4 samples x 128 units x 2
+_USTAT_WORDS = 1 << 17            # int64 words per arena (1 MiB): ~35 producers x 8 replicas x 4 samples x <= 128 units x 2
 _ustat_arenas = {}
 
 
@@ -413,23 +413,26 @@ def ustat_begin(device, unit: int):
     if not USTAT or unit <= 0 or torch.device(device).type != "cuda":
         _tls.ustat = None
         return
-    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream, _domain())
-    buf = _ustat_arenas.get(key)
-    if buf is None:
-        buf = torch.zeros(_USTAT_WORDS, dtype=torch.int64, device=device)
-        _ustat_arenas[key] = buf
-        if torch.cuda.is_current_stream_capturing():
-            _ws_capture_keep.append(buf)
-    st = getattr(_tls, "ustat", None)
-    used = st["off"] if (st is not None and st["buf"] is buf) else _USTAT_WORDS
-    buf[:max(used, 2)].zero_()          # what the previous forward on this arena used (the whole arena the first time)
-    _tls.ustat = {"buf": buf, "off": 0, "unit": int(unit), "last": used}
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream, _domain(), capturing)
+    ent = _ustat_arenas.get(key)
+    if ent is None:
+        # (allocated inside a capture, the zero fill is part of the graph: every replay starts from a clean arena; such a buffer is
+        #  never released -- its address is baked into the graph, see _workspace)
+        ent = _ustat_arenas[key] = {"buf": torch.zeros(_USTAT_WORDS, dtype=torch.int64, device=device), "used": 0}
+        if capturing:
+            _ws_capture_keep.append(ent["buf"])
+            ent["used"] = _USTAT_WORDS          # a second capture on this stream zeroes everything: it cannot know what the first used
+    elif ent["used"]:
+        ent["buf"][:ent["used"]].zero_()        # what the previous forward on this arena added to
+    _tls.ustat = {"buf": ent["buf"], "off": 0, "unit": int(unit), "ent": ent}
 
 
 def ustat_end():
     st = getattr(_tls, "ustat", None)
-    if st is not None:
+    if st is not None and not st.get("closed"):
         st["closed"] = True
+        st["ent"]["used"] = max(st["ent"]["used"], st["off"])
 
 
 def _ustat_alloc(B: int, nout: int):
@@ -438,12 +441,15 @@ def _ustat_alloc(B: int, nout: int):
         return None
     unit = st["unit"]
     units = (nout + unit - 1) // unit
-    n = USTAT_NREP * B * units * 2
+    nrep = USTAT_NREP                 # replicas spread the same-address contention; more samples already spread it
+    while nrep > 1 and nrep * B > 4 * USTAT_NREP:
+        nrep //= 2
+    n = nrep * B * units * 2
     if st["off"] + n > st["buf"].numel():
         return None
     u = st["buf"][st["off"]:st["off"] + n]
     st["off"] += n
-    return u, unit, units, USTAT_NREP
+    return u, unit, units, nrep
 
 
 def _colstats_drop(out: torch.Tensor):
@@ -808,7 +814,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
     if segs is not None:
         for i, (st, rpb, cseg, us) in enumerate(segs):
             p.colstats[i].stats, p.colstats[i].ld, p.colstats[i].rows_per_block, p.colstats[i].C = st.data_ptr(), st.shape[1], rpb, cseg
-            if us is not None and us[0].shape[0] == USTAT_NREP * B * us[2] * 2:
+            if us is not None and us[0].shape[0] == us[3] * B * us[2] * 2:
                 p.colstats[i].ustats, p.colstats[i].unit, p.colstats[i].units, p.colstats[i].nrep = us[0].data_ptr(), us[1], us[2], us[3]
         p.variant = 1                       # the multi-launch skeleton (statistics pass replaced by the finalise)
     cnt = _tile_counters(x.device) if (GN_FUSED_FINALIZE and B <= _N_COUNTERS) else None

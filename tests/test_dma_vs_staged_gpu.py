@@ -75,7 +75,7 @@ def test_every_headline_launch_dma_tile_equals_register_staged_tile(headline_log
         for form in ("f32", "bf16"):
             for side in ("dma", "staged"):
                 q = _clone(p)
-                q.rowstat_out = q.colstat_out = q.prefetch = None
+                q.rowstat_out = q.colstat_out = q.prefetch = q.ustat_out = None
                 q.rowstat_slots = q.colstat_ld = 0
                 q.prefetch_bytes = 0
                 if side == "staged":

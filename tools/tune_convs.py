@@ -27,6 +27,7 @@ def clone_params(p):
     # the statistics outputs are sized for the tile of the recorded launch (slots / row blocks depend on the tile):
     # candidates are timed without them
     q.rowstat_out, q.rowstat_slots, q.colstat_out, q.colstat_ld = None, 0, None, 0
+    q.ustat_out = None          # (unit statistics go with colstat_out: AptpConvGemmParams.ustat_out)
     return q
 
 

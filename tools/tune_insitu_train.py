@@ -174,7 +174,7 @@ def main():
         q.tile_counters = counters.data_ptr() if (cd[1] > 1 and (cd[3] or cd[0] >= ops.SK_TILE_FIRST)) else None
         q.prefetch, q.prefetch_bytes = None, 0
         q.y = ws.data_ptr() + (512 << 20)           # (never write through the recorded output pointer: scratch output instead)
-        q.rowstat_out = q.colstat_out = None
+        q.rowstat_out = q.colstat_out = q.ustat_out = None
         q.residual = q.depth_in = None
         if cd[1] > 1 and lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(q)) > (512 << 20):
             return False

@@ -464,11 +464,20 @@ class GraphedPrunerStep(PrunerStep):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._cap = None
-        self.stream_probe = []          # what graph_utils.concurrent_stream measured when it chose the teacher's side stream
+        self.stream_probe = []          # what graph_utils.concurrent_stream measured when it chose the teacher's / router's side streams
+        self.overlap_router = os.environ.get("APTP_OVERLAP_ROUTER", "1") != "0"
+        self._finish_hooks = []
+
+    def remove_hooks(self):
+        super().remove_hooks()
+        for h in self._finish_hooks:
+            h.remove()
+        self._finish_hooks = []
 
     # ---- capture ------------------------------------------------------------------------------------------------
     def _snr_weights(self, timesteps):
-        """min-SNR-gamma weights (trainer.py:1203-1213); host tables are involved, so this stays outside the graphs"""
+        """min-SNR-gamma weights (trainer.py:1203-1213); the alpha-bar table lives on the device (_schedule_on), so the captured
+        teacher graph computes them from the staged timesteps"""
         cfg = self.cfg
         if cfg.snr_gamma is None:
             return torch.ones(timesteps.shape[0], device=timesteps.device)
@@ -547,6 +556,9 @@ class GraphedPrunerStep(PrunerStep):
         def teacher():
             # own split-K counters / scratch: this graph replays NEXT TO the student's forward (ops.scratch_domain)
             with torch.no_grad(), ops.scratch_domain("teacher"):
+                # the min-SNR weights of this batch: a dozen tiny launches that only the loss terms read -- inside this graph they
+                # run on the side stream next to the router instead of ahead of everything on the caller's stream (0.8 ms of a step)
+                st["snr_w"].copy_(self._snr_weights(st["timesteps"]))
                 pred = self.unet(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
                 return pred, dict(self.block_activations)
 
@@ -684,7 +696,14 @@ class GraphedPrunerStep(PrunerStep):
         with torch.cuda.graph(g_bwd, pool=g_fwd.pool()):
             bwd(r)
         torch.set_rng_state(host_rng)
-        cap["router"] = dict(g_fwd=g_fwd, g_bwd=g_bwd, out=r, text=text, tape=tape, optimizer=optimizer, pretrain=bool(pretrain))
+        cap["router"] = dict(g_fwd=g_fwd, g_bwd=g_bwd, out=r, text=text, tape=tape, optimizer=optimizer, pretrain=bool(pretrain),
+                             stream=concurrent_stream(log=self.stream_probe), ev_entry=torch.cuda.Event(), ev_code=torch.cuda.Event(),
+                             ev_bwd=torch.cuda.Event(), ev_tail=torch.cuda.Event(), pending=False)
+        if not self._finish_hooks:
+            # anything that reads the router's parameters outside the captured step first waits for the pending optimizer step
+            for m in (self.hyper_net, self.quantizer):
+                self._finish_hooks.append(m.register_forward_pre_hook(lambda *_a, **_k: self.finish()))
+                self._finish_hooks.append(m.register_state_dict_pre_hook(lambda *_a, **_k: self.finish()))
 
     def graph_nodes(self):
         """nodes (kernel launches + torch's few memcpy / memset nodes) of the three captured graphs, when they were kept
@@ -748,8 +767,7 @@ class GraphedPrunerStep(PrunerStep):
             for k, src in (("noisy_latents", noisy_latents), ("timesteps", timesteps),
                            ("encoder_hidden_states", encoder_hidden_states), ("target", target)):
                 cap["st"][k].copy_(src)
-            cap["st"]["snr_w"].copy_(self._snr_weights(timesteps))
-        side = cap["side"]
+        side = cap["side"]                       # (the min-SNR weights are computed from the staged timesteps inside g_teacher)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             cap["g_teacher"].replay()
@@ -769,6 +787,7 @@ class GraphedPrunerStep(PrunerStep):
         rt = cap.get("router") if cap is not None else None
         if rt is not None and rt["optimizer"] is optimizer and rt["pretrain"] == bool(pretrain) and self.hyper_net.training:
             return self._train_step_captured_router(batch)
+        self.finish()
         optimizer.zero_grad(set_to_none=True)
         out = self.step(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"],
                         batch["mpnet_embeddings"], batch["target"], pretrain=pretrain)
@@ -779,24 +798,52 @@ class GraphedPrunerStep(PrunerStep):
 
     def _train_step_captured_router(self, batch: dict):
         """the whole step from five graphs: [teacher || router] -> student forward -> losses + U-Net backward -> chain rule into the
-        router + optimizer.  The host only stages the batch and refills the Gumbel uniforms from its generator."""
+        router + optimizer.  The host only stages the batch and refills the Gumbel uniforms from its generator.
+
+        The two router graphs are chains of a few hundred tiny launches (0.9 + 1.3 ms during which the chip idles).  With
+        overlap_router (default) they replay on a stream of their own: the NEXT step's batch staging and teacher forward do not
+        queue behind this step's router backward + optimizer, they run next to it; the student's forward waits for the code
+        (ev_code), the router backward for the U-Net backward (ev_bwd).  Reading router parameters on another stream afterwards
+        needs finish() -- the router modules' forward / state_dict hooks and the eager train_step call it."""
         cfg, cap = self.cfg, self._cap
         rt = cap["router"]
+        main = torch.cuda.current_stream()
+        rs = rt["stream"] if self.overlap_router else main
+        rt["ev_entry"].record(main)                           # the batch tensors were produced on the caller's stream
         self._stage_batch_and_launch_teacher(batch["noisy_latents"], batch["timesteps"], batch["encoder_hidden_states"], batch["target"])
-        with torch.no_grad():
-            rt["text"].copy_(batch["mpnet_embeddings"])
-        rt["tape"].refill()                                   # host-RNG stream, consumed exactly as the eager calls consume it
-        rt["g_fwd"].replay()                                  # router -> architecture code installed for the student
+        with torch.cuda.stream(rs):
+            rs.wait_event(rt["ev_entry"])
+            with torch.no_grad():
+                rt["text"].copy_(batch["mpnet_embeddings"])
+            rt["tape"].refill()                               # host-RNG stream, consumed exactly as the eager calls consume it
+            rt["g_fwd"].replay()                              # router -> architecture code installed for the student
+            rt["ev_code"].record(rs)
+        main.wait_event(rt["ev_code"])
         cap["g_student"].replay()
-        torch.cuda.current_stream().wait_stream(cap["side"])
+        main.wait_stream(cap["side"])
         cap["g_student_bwd"].replay()
-        rt["g_bwd"].replay()                                  # d(router losses + U-Net terms)/d(router), optimizer step
+        rt["ev_bwd"].record(main)
+        with torch.cuda.stream(rs):
+            rs.wait_event(rt["ev_bwd"])
+            rt["g_bwd"].replay()                              # d(router losses + U-Net terms)/d(router), optimizer step
+            rt["ev_tail"].record(rs)
+        rt["pending"] = rs is not main
         r = rt["out"]
+        # (the router graph's outputs were complete at ev_code; the next router forward, which overwrites them, waits for the next
+        #  step's ev_entry, i.e. for these clones)
         unet_loss = cap["loss"] + cfg.distillation_weight * cap["dist"] + cfg.block_weight * cap["blk"]
         return {"loss": (r["router_loss"].detach() + unet_loss).clone(), "diff_loss": cap["loss"].clone(),
                 "distillation_loss": cap["dist"].clone(), "block_loss": cap["blk"].clone(),
                 "contrastive_loss": r["contrastive_loss"].detach().clone(), "resource_loss": r["resource_loss"].detach().clone(),
                 "resource_ratio": r["ratios"].mean().detach(), "arch_vector_quantized": r["arch_vector_quantized"].detach().clone()}
+
+    def finish(self):
+        """make the current stream wait for the router backward + optimizer of the last captured step (they run on the router's own
+        stream); called by the router modules' forward / state_dict hooks and by the eager paths of this class"""
+        rt = self._cap.get("router") if self._cap is not None else None
+        if rt is not None and rt.get("pending"):
+            torch.cuda.current_stream().wait_event(rt["ev_tail"])
+            rt["pending"] = False
 
 
 def synthetic_batch(batch: int, latent: int, device, seed: int = 1234, cross_dim: int = 1024, text_dim: int = 768):
@@ -937,7 +984,9 @@ class GraphedFineTunerStep(FineTunerStep):
         self.opt_kw = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
         self.optimizer = None
         self._cap = None
-        self.stream_probe = []          # what graph_utils.concurrent_stream measured when it chose the teacher's side stream
+        self.stream_probe = []          # what graph_utils.concurrent_stream measured when it chose the teacher's / router's side streams
+        self.overlap_router = os.environ.get("APTP_OVERLAP_ROUTER", "1") != "0"
+        self._finish_hooks = []
 
     def _losses(self, model_pred, full_pred, w, target):
         cfg = self.cfg
@@ -993,6 +1042,7 @@ class GraphedFineTunerStep(FineTunerStep):
         def teacher_fwd():
             # own split-K counters / scratch: this graph replays NEXT TO the previous step's optimizer tail (ops.scratch_domain)
             with torch.no_grad(), ops.scratch_domain("teacher"):
+                st["snr_w"].copy_(self._snr_weights(st["timesteps"]))      # (min-SNR weights: read by the loss terms only)
                 fp = self.teacher(st["noisy_latents"], st["timesteps"], st["encoder_hidden_states"]).sample.detach()
             return fp, dict(self.acts_t)
 
@@ -1117,8 +1167,7 @@ class GraphedFineTunerStep(FineTunerStep):
         with torch.no_grad():
             for k in ("noisy_latents", "timesteps", "encoder_hidden_states", "target"):
                 cap["st"][k].copy_(batch[k])
-            cap["st"]["snr_w"].copy_(self._snr_weights(batch["timesteps"]))
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream()       # (the min-SNR weights are computed from the staged timesteps inside g_teacher)
         side = cap["side"] if self.overlap_teacher else main
         side.wait_stream(main)                   # (the batch copies above)
         with torch.cuda.stream(side):

@@ -331,10 +331,12 @@ def test_captured_router_trains_like_the_eager_router(cuda):
     hn.to(cuda); qz.to(cuda)
     hn.train(); qz.train()
     hn2, qz2 = copy.deepcopy(hn), copy.deepcopy(qz)
+    hn3, qz3 = copy.deepcopy(hn), copy.deepcopy(qz)
     batches = [synthetic_batch(4, 16, cuda, seed=s, cross_dim=cfg.cross_attention_dim, text_dim=32) for s in (3, 4, 5)]
 
-    def run(hn_, qz_, captured):
+    def run(hn_, qz_, captured, overlap_router=True):
         step = GraphedPrunerStep(unet, hn_, qz_)
+        step.overlap_router = overlap_router
         step.count_macs(16)
         opt = torch.optim.AdamW(step.trainable_parameters(), lr=1e-3, capturable=True)
         p0 = torch.cat([p.detach().flatten().clone() for p in step.trainable_parameters()])
@@ -348,7 +350,9 @@ def test_captured_router_trains_like_the_eager_router(cuda):
         for b in batches:
             o = step.train_step(opt, b)
             losses.append({k: float(o[k]) for k in ("loss", "diff_loss", "distillation_loss", "block_loss", "resource_loss", "contrastive_loss")})
-        torch.cuda.synchronize()
+        # the router's backward + optimizer replay on the router's own stream (overlap_router): finish() orders this stream behind them
+        assert bool(step._cap["router"] and step._cap["router"]["pending"]) == (captured and overlap_router)
+        step.finish()
         step.remove_hooks()
         return losses, torch.cat([p.detach().flatten().clone() for p in step.trainable_parameters()]), p0, step
 
@@ -359,6 +363,9 @@ def test_captured_router_trains_like_the_eager_router(cuda):
             assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-5, (k, a, b)
     assert float((pa - p0).abs().max()) > 0
     assert rel_l2(pb - p0, pa - p0) <= 2e-2, rel_l2(pb - p0, pa - p0)
+    # the router graphs on their own stream (next to the following step's staging + teacher) or on the caller's: the same bits
+    lc, pc, _, _ = run(hn3, qz3, True, overlap_router=False)
+    assert lc == lb and torch.equal(pc, pb)
 
 
 def test_side_stream_is_chosen_by_an_overlap_probe(cuda):

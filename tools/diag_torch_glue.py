@@ -20,7 +20,8 @@ COPIES = "--copies" in sys.argv  # only copy-like ops, from 16 K elements up
 if COPIES:
     THRESH = 1 << 14
 ALL = "--all" in sys.argv        # every torch op that launches something, ranked by COUNT (the launch diet's view)
-if ALL:
+GRAPHED = "--graphed" in sys.argv  # the ops torch records INTO the three captured U-Net graphs of GraphedPrunerStep (by op, site, shape)
+if ALL or GRAPHED:
     THRESH = 1
 dev = torch.device("cuda:0")
 unet = UNet2DConditionModelGated().init_synthetic(seed=0).to(dev)
@@ -66,10 +67,14 @@ class Big(TorchDispatchMode):
             return out
         if COPIES and not any(k in name for k in ("clone", "copy", "contiguous", "cat", "pad", "stack", "index", "zeros", "fill")):
             return out
+        if GRAPHED and not torch.cuda.is_current_stream_capturing():
+            return out
         if t is not None and t.is_cuda and t.numel() >= THRESH and not any(s in name for s in ("view", "permute", "slice", "detach",
                                                                                               "t.default", "alias", "expand", "select", "unsqueeze", "squeeze", "as_strided", "reshape", "transpose", "narrow", "split", "unbind")):
             fr = [f for f in traceback.extract_stack() if "diffusion_pruning_amd" in f.filename]
             where = tuple((f.filename.split("/")[-1], f.lineno) for f in fr[-2:]) if fr else ("autograd engine", 0)
+            if GRAPHED:
+                where = (where, tuple(t.shape))
             self.c[(name, where)] += 1
             self.bytes[(name, where)] += t.numel() * t.element_size()
         return out
@@ -83,13 +88,20 @@ def run():
     out["loss"].backward()
 
 
-run()
-torch.cuda.synchronize()
-with Big() as big:
+if GRAPHED:
+    from diffusion_pruning_amd.train_step import GraphedPrunerStep
+    gstep = GraphedPrunerStep(unet, hn, qz)
+    gstep.count_macs(64)
+    with Big() as big:
+        gstep.capture(b)
+else:
     run()
+    torch.cuda.synchronize()
+    with Big() as big:
+        run()
 torch.cuda.synchronize()
 tot = 0
-for k, n in sorted(big.c.items(), key=lambda kv: (-kv[1] if ALL else -big.bytes[kv[0]]))[:(70 if ALL else 40)]:
+for k, n in sorted(big.c.items(), key=lambda kv: (-kv[1] if (ALL or GRAPHED) else -big.bytes[kv[0]]))[:(120 if GRAPHED else 70 if ALL else 40)]:
     print(f"{n:4d} x {big.bytes[k] / n / 1e6:7.1f} MB  {k[0]:36s} {k[1]}")
     tot += big.bytes[k]
 print("total output bytes of big torch ops per step: %.1f MB; %d torch ops counted" % (tot / 1e6, sum(big.c.values())))

@@ -7,6 +7,7 @@
 //                               LDS image written transposed with the matching key permutation)
 // K/V tiles are prefetched into registers while the previous tile computes (issue-early / write-late).
 #include "aptp_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -547,6 +548,322 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const AttnK p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form of the double-buffered two-group kernel (AptpAttentionParams.variant = 6; long key ranges with
+// Lk % 128 == 0, Lq % 128 == 0).  In attn_fwd_pp_kernel<false> a wave runs QK^T -> softmax -> PV strictly in sequence and the
+// two waves of a SIMD do so in lock step (one barrier per key tile), so the matrix pipe idles during both waves' softmax
+// (~950 issue cycles of VALU per wave and tile against 16 MFMAs of 32) and the vector pipe during both waves' MFMAs.  Here a
+// wave computes the scores of tile i+1 (8 MFMAs that depend on nothing the vector unit is working on) WHILE it runs the
+// softmax of tile i, and P.V of tile i while it transposes / stages the following K and V tiles: every MFMA has independent
+// vector work next to it in the same basic block.  K is staged two tiles ahead, V one (separate rings, still one barrier
+// per tile); the loop is unrolled by two so that the two score accumulators swap roles without moves; tile indices are
+// clamped instead of branched on, so that the body stays one scheduling region per phase.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
+  constexpr int KV_ELEMS = 2 * 64 * 64;                 // one K image + one V^T image
+  constexpr int MERGE_FLOATS = 256 * 34;
+  constexpr int LDS_BYTES = (4 * KV_ELEMS * 2 > MERGE_FLOATS * 4) ? 4 * KV_ELEMS * 2 : MERGE_FLOATS * 4;   // 64 KiB
+  __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+  const int grp = (int)(threadIdx.x >> 8);
+  __bf16* const kv_base = reinterpret_cast<__bf16*>(lds_raw) + grp * 2 * KV_ELEMS;    // [buffer][K | V^T]
+
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const __bf16* qp = p.q + (int64_t)b * p.qsb + (int64_t)h * 64;
+  const __bf16* kp = p.k + (int64_t)b * p.ksb + (int64_t)h * 64;
+  const __bf16* vp = p.v + (int64_t)b * p.vsb + (int64_t)h * 64;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + (int64_t)(q0 + lq) * p.qsl + 16 * s + 8 * hh));
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(qf[s]));       // retire the Q loads here (see attn_fwd_pp_kernel)
+
+  const int chunk = tid & 7;
+  const int krow = tid >> 3;
+  u32x4 kra[2], vra[2], krb[2], vrb[2];        // two register sets: a tile's K / V are requested ~1.75 tile periods before their LDS store
+
+  const int n = (p.Lk / 64) / 2;                   // tiles per group (host: Lk % 128 == 0, n >= 2)
+  const int t_begin = grp * n;
+  const int t_last = t_begin + n - 1;
+
+  // wave-uniform tile base + 32-bit per-thread byte offset (host: 64 rows of K / V span < 2 GiB): no 64-bit vector address math
+  uint32_t koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    koff[i] = (uint32_t)(((krow + 32 * i) * p.ksl + chunk * 8) * 2);
+    voff[i] = (uint32_t)(((2 * krow + i) * p.vsl + chunk * 8) * 2);
+  }
+  auto load_k = [&](u32x4 (&kreg)[2], int tile) {
+    tile = __builtin_amdgcn_readfirstlane(tile < t_last ? tile : t_last);
+    const char* base = reinterpret_cast<const char*>(kp + (int64_t)tile * 64 * p.ksl);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(base + koff[i]);
+  };
+  auto load_v = [&](u32x4 (&vreg)[2], int tile) {
+    tile = __builtin_amdgcn_readfirstlane(tile < t_last ? tile : t_last);
+    const char* base = reinterpret_cast<const char*>(vp + (int64_t)tile * 64 * p.vsl);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(base + voff[i]);
+  };
+  // max(a, b, c) without the canonicalising v_max hipcc puts in front of fmaxf on MFMA outputs; the other half-wave's value
+  // (one asm statement per 8 scores: between separate statements hipcc puts an s_nop)
+  auto max8 = [](float m, const float* v) {
+    asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
+        : "+v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+    return m;
+  };
+  // (x of lanes 0-31 in both halves, x of lanes 32-63 in both halves): v_permlane32_swap, no LDS round trip
+  auto halves = [](float x, float& lo, float& hi) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    lo = __builtin_bit_cast(float, (unsigned)r[0]);
+    hi = __builtin_bit_cast(float, (unsigned)r[1]);
+  };
+  auto store_k = [&](const u32x4 (&kreg)[2], int buf) {
+    __bf16* Ks = kv_base + buf * KV_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = krow + 32 * i;
+      const int sw = chunk ^ ((r >> 1) & 7);
+      *reinterpret_cast<u32x4*>(Ks + r * 64 + sw * 8) = kreg[i];
+    }
+  };
+  auto store_v = [&](const u32x4 (&vreg)[2], int buf) {
+    __bf16* Vt = kv_base + buf * KV_ELEMS + 64 * 64;
+    const int pos = vt_pos(2 * krow);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = chunk * 8 + e;
+      const int sw = (pos >> 3) ^ ((d >> 1) & 7);
+      const uint32_t a = vreg[0][e >> 1], bb = vreg[1][e >> 1];
+      const uint32_t w = (e & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
+      *reinterpret_cast<uint32_t*>(Vt + d * 64 + sw * 8 + (pos & 7)) = w;
+    }
+  };
+  f32x16 oacc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // hipcc on its own emits each phase as [fragment reads + MFMAs][all the vector work]: the in-order wave then sits through
+  // its 8 MFMAs (256 cycles) before it issues a single softmax instruction.  The body below is written slot by slot -- one
+  // MFMA plus >= 32 issue cycles of independent vector work -- and sched_barrier(0) between the slots pins that order.
+#define APTP_SLOT_END() __builtin_amdgcn_sched_barrier(0)
+#ifndef APTP_ATTN_ABL
+#define APTP_ATTN_ABL 0      // timing experiments only (wrong results): 1 no exp2, 2 no loop barrier, 4 no LDS staging stores, 8 no MFMAs,
+#endif                       // 16 fragments from registers (no LDS fragment reads), 64 per-phase cycle totals of block 0 into p.lse
+  unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define APTP_ATTN_STAMP(i) do { if constexpr ((APTP_ATTN_ABL & 64) != 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    if ((i) > 0) st_acc[(i) - 1] += t_ - st_prev; st_prev = t_; } } while (0)
+  // K fragment j = (s, t) = (j >> 1, j & 1) of the tile in K buffer `buf`; V fragment j = (t, s2, u) = (j >> 2, (j >> 1) & 1, j & 1)
+  auto read_k = [&](bf16x8 (&kf)[8], int buf) {
+    const __bf16* Ks = kv_base + buf * KV_ELEMS;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r_ = 32 * (j & 1) + lq;
+      const int sw = (2 * (j >> 1) + hh) ^ ((r_ >> 1) & 7);
+      kf[j] = *reinterpret_cast<const bf16x8*>(Ks + r_ * 64 + sw * 8);
+    }
+  };
+  auto read_v = [&](bf16x8 (&vf)[8], int buf) {
+    const __bf16* Vt = kv_base + buf * KV_ELEMS + 64 * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = 32 * (j & 1) + lq;
+      const int sw = (4 * (j >> 2) + 2 * ((j >> 1) & 1) + hh) ^ ((d >> 1) & 7);
+      vf[j] = *reinterpret_cast<const bf16x8*>(Vt + d * 64 + sw * 8);
+    }
+  };
+  // one tile: scores of the NEXT tile (K buffer kbuf) into nxt while the softmax of cur runs; P.V of cur (V buffer vbuf) while
+  // K(i+2) / V(i+1) are written to LDS.  WITH_NEXT = false: the last tile of the group (no scores, no staging).
+  // kreg / vreg: K(i+2) / V(i+1), requested during the previous tile, stored here; kreq / vreq: K(i+3) / V(i+2), requested here
+  auto tile_step = [&](auto with_next, f32x16 (&cur)[2], f32x16 (&nxt)[2], int kbuf, int vbuf, int kst, int vst, int tk, int tv,
+                       const u32x4 (&kreg)[2], const u32x4 (&vreg)[2], u32x4 (&kreq)[2], u32x4 (&vreq)[2]) {
+    constexpr bool WITH_NEXT = decltype(with_next)::value;
+    bf16x8 kf[8], vf[8], pf[4];
+    APTP_ATTN_STAMP(0);
+    if constexpr (WITH_NEXT) {
+      load_k(kreq, tk);
+      load_v(vreq, tv);
+      if constexpr ((APTP_ATTN_ABL & 16) != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] = qf[j & 3];
+      } else read_k(kf, kbuf);
+    }
+    // score MFMA j of the next tile (accumulator t = j & 1, Q fragment s = j >> 1)
+    auto qk = [&](int j) {
+      if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 8)) nxt[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j >> 1], j < 2 ? zero16 : nxt[j & 1], 0, 0, 0);
+    };
+    auto pv = [&](int j) { if constexpr (!(APTP_ATTN_ABL & 8)) oacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j >> 1], oacc[j & 1], 0, 0, 0); };
+    float rs = 0.f, m_new;
+    // half a P fragment: exp2 / row sum / bf16 pack of 4 scores (fragment q = (t, s2) = (q >> 1, q & 1), half hf)
+    auto exp4 = [&](int q, int hf) {
+#pragma unroll
+      for (int j = 4 * hf; j < 4 * hf + 4; ++j) {
+        const float x = __builtin_fmaf(cur[q >> 1][8 * (q & 1) + j], p.c, -m_new);
+        const float e = (APTP_ATTN_ABL & 1) ? x : __builtin_amdgcn_exp2f(x);
+        rs += e;
+        pf[q][j] = (__bf16)e;
+      }
+    };
+    // one d of the transposed V(i+1) image
+    __bf16* Vst = kv_base + vst * KV_ELEMS + 64 * 64;
+    const int pos = vt_pos(2 * krow);
+    auto stage_v = [&](int j) {
+      if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 4)) {
+        const int d = chunk * 8 + j;
+        const int sw = (pos >> 3) ^ ((d >> 1) & 7);
+        const uint32_t a = vreg[0][j >> 1], bb = vreg[1][j >> 1];
+        const uint32_t w = (j & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
+        *reinterpret_cast<uint32_t*>(Vst + d * 64 + sw * 8 + (pos & 7)) = w;
+      }
+    };
+    // A: running maximum (2 slots of 16 scores) next to score MFMAs 0, 1
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      qk(j);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float v8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v8[r] = cur[j][8 * hf + r];
+        mx = max8(mx, v8);
+      }
+      APTP_SLOT_END();
+    }
+    APTP_ATTN_STAMP(1);
+    if constexpr ((APTP_ATTN_ABL & 16) != 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vf[j] = qf[j & 3];
+    } else read_v(vf, vbuf);
+    float mlo, mhi;
+    halves(mx, mlo, mhi);
+    mx = fmaxf(mlo, mhi) * p.c;
+    // The reference maximum moves only when the tile's maximum exceeds it by more than 2^6: P then stays <= 64 (exact in bf16's
+    // range, row sums <= 64 * Lk in fp32) and O is rescaled -- 16 packed multiplies, ~20 % of a tile's vector work -- only in the
+    // first tiles of a row instead of in nearly every tile (any tile in which one of the wave's 32 queries sees a new maximum).
+    m_new = mx > m_run + 6.0f ? mx : m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+    }
+    APTP_ATTN_STAMP(2);
+    // C0: P fragment 0 next to score MFMAs 2, 3
+    qk(2); exp4(0, 0); APTP_SLOT_END();
+    qk(3); exp4(0, 1); APTP_SLOT_END();
+    APTP_ATTN_STAMP(3);
+    // C1-C3: P fragment q next to the P.V MFMAs of fragment q - 1
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      pv(2 * q - 2); exp4(q, 0); APTP_SLOT_END();
+      pv(2 * q - 1); exp4(q, 1); APTP_SLOT_END();
+    }
+    APTP_ATTN_STAMP(4);
+    float slo, shi;
+    halves(rs, slo, shi);
+    l_run = l_run * alpha + (slo + shi);
+    m_run = m_new;
+    // D: the last two P.V MFMAs and score MFMAs 4-7 next to the transposed store of V(i+1) (one d per slot), K(i+2) and the requests
+    pv(6); stage_v(0); stage_v(1); APTP_SLOT_END();
+    pv(7); stage_v(2); if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 4)) store_k(kreg, kst); APTP_SLOT_END();      // K(i+2) over K(i) (past the end: a clamped copy nobody reads)
+    qk(4); stage_v(3); stage_v(4); APTP_SLOT_END();
+    qk(5); stage_v(5); APTP_SLOT_END();
+    qk(6); stage_v(6); stage_v(7); APTP_SLOT_END();
+    qk(7);
+    APTP_ATTN_STAMP(5);
+    if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 2)) __syncthreads();
+    APTP_ATTN_STAMP(6);
+  };
+
+  // prologue: K(0), V(0), K(1) staged; S(0) computed; K(2), V(1) requested
+  load_k(kra, t_begin); load_v(vra, t_begin);
+  store_k(kra, 0); store_v(vra, 0);
+  load_k(kra, t_begin + 1);
+  store_k(kra, 1);
+  __syncthreads();
+  f32x16 sa[2], sb[2];
+  {
+    bf16x8 kf[8];
+    read_k(kf, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sa[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j >> 1], j < 2 ? zero16 : sa[j & 1], 0, 0, 0);
+  }
+  load_k(kra, t_begin + 2); load_v(vra, t_begin + 1);
+  __syncthreads();                                  // every wave has read K(0): its buffer may be overwritten from here on
+
+  // step i: S(i+1) next to softmax(i); P.V(i) next to staging K(i+2) -> K buffer i&1, V(i+1) -> V buffer (i+1)&1, then K(i+3), V(i+2) requested
+  auto body = [&](int i, f32x16 (&cur)[2], f32x16 (&nxt)[2], u32x4 (&k0)[2], u32x4 (&v0)[2], u32x4 (&k1)[2], u32x4 (&v1)[2]) {
+    tile_step(std::true_type{}, cur, nxt, (i + 1) & 1, i & 1, i & 1, (i + 1) & 1, t_begin + i + 3, t_begin + i + 2, k0, v0, k1, v1);
+  };
+  int i = 0;
+  for (; i + 2 < n; i += 2) {
+    body(i, sa, sb, kra, vra, krb, vrb);
+    body(i + 1, sb, sa, krb, vrb, kra, vra);
+  }
+  if (i + 1 < n) {                                  // n even: one more full step, the last tile's scores are in sb
+    body(i, sa, sb, kra, vra, krb, vrb);
+    tile_step(std::false_type{}, sb, sa, 0, (i + 1) & 1, 0, 0, 0, 0, kra, vra, krb, vrb);
+  } else {
+    tile_step(std::false_type{}, sa, sb, 0, i & 1, 0, 0, 0, 0, kra, vra, krb, vrb);
+  }
+
+  // merge the two key-range groups: group 1 publishes (m, l, O) per lane, group 0 combines
+  float* mg = reinterpret_cast<float*>(lds_raw);
+  __syncthreads();
+  if (grp == 1) {
+    float* dst = mg + tid * 34;
+    dst[0] = m_run; dst[1] = l_run;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[2 + u * 16 + r] = oacc[u][r];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  {
+    const float* src = mg + tid * 34;
+    const float m1 = src[0], l1 = src[1];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    l_run = l_run * a0 + l1 * a1;
+    m_run = m;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[u][r] = oacc[u][r] * a0 + src[2 + u * 16 + r] * a1;
+  }
+  const int qrow = q0 + lq;
+  if constexpr ((APTP_ATTN_ABL & 64) != 0) {
+    if (p.lse && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
+      for (int j = 0; j < 6; ++j) p.lse[wave * 8 + j] = (float)st_acc[j] / (float)n;
+  } else if (p.lse && hh == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run + log2f(l_run);
+  const float inv = 1.0f / l_run;
+  __bf16* op = p.o + (int64_t)b * p.osb + (int64_t)qrow * p.osl + (int64_t)h * 64;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * u + 8 * g + 4 * hh;
+      uint2 w;
+      w.x = pack_bf16x2(oacc[u][4 * g + 0] * inv, oacc[u][4 * g + 1] * inv);
+      w.y = pack_bf16x2(oacc[u][4 * g + 2] * inv, oacc[u][4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(op + d) = w;
+    }
+}
+
 }  // namespace
 
 extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream) {
@@ -574,6 +891,15 @@ extern "C" int aptp_attention(const AptpAttentionParams* p, aptp_stream_t stream
   const int64_t waves = (int64_t)grid.x * grid.y * grid.z * 4;
   const int ntiles = (p->Lk + 63) / 64;
   const bool two_groups = ntiles >= 2 && p->variant != 5 && (waves < 2 * 1024 || ntiles >= 32 || p->variant != 0);
+  // Software-pipelined two-group form (round 4): whole 128-row query blocks, an even number >= 4 of whole key tiles, K / V rows of a
+  // tile within 2 GiB.  Faster than every other form wherever it applies (tools/bench_attn.py, MI355X: level-64 self-attention
+  // 51-53 us against 64-68 masked and 130-135 against 168 dense; 1024 keys 16.3 against 18.8; 256 keys 7.5 against 8.0).
+  if ((p->variant == 0 || p->variant == 6) && p->Lk % 128 == 0 && p->Lk >= 256 && p->Lq % 128 == 0 &&
+      p->k_stride_l * 64 * 2 < (1ll << 31) && p->v_stride_l * 64 * 2 < (1ll << 31)) {
+    hipLaunchKernelGGL(attn_fwd_sp_kernel, grid, dim3(512), 0, (hipStream_t)stream, k);
+    APTP_LAUNCH_CHECK();
+    return APTP_OK;
+  }
   if (two_groups) {
     // The staggered form measured 5-10 % SLOWER than the lock-step one on MI355X (level-64 self-attention of SD-2.1:
     // 75.9 vs 69.3 us; tools/bench_attn.py), so it is opt-in only.

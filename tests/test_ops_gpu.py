@@ -51,9 +51,10 @@ def both_gn_forms(ops, request):
     ops.GN_FUSED_FINALIZE = False
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["attn-auto", "attn-staggered", "attn-4groups", "attn-2groups", "attn-dbuf"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 6], ids=["attn-auto", "attn-staggered", "attn-4groups", "attn-2groups", "attn-dbuf", "attn-swpipe"])
 def both_attn_forms(ops, request):
-    """key-split attention in its forms: auto, two groups one phase apart, four groups, two lock-step groups"""
+    """key-split attention in its forms: auto (= the software-pipelined kernel where whole 128-blocks allow it), two groups one phase
+    apart, four groups, two lock-step groups, double-buffered, software-pipelined"""
     ops.ATTN_VARIANT = request.param
     yield request.param
     ops.ATTN_VARIANT = 0
@@ -821,12 +822,14 @@ def test_attention(ops, cuda, case, both_attn_forms):
     assert e <= 6e-3, f"rel-L2 {e:.3e}"   # P is rounded to bf16 before P.V (as any bf16 flash kernel does)
 
 
-def test_attention_fused_qkv_views_and_spike(ops, cuda, both_attn_forms):
-    """q/k/v as column slices of one fused buffer; one key spiked so the running max jumps mid-sequence"""
+@pytest.mark.parametrize("L,spike", [(320, 6.0), (512, 6.0), (512, 1.6), (1024, 30.0)])
+def test_attention_fused_qkv_views_and_spike(ops, cuda, both_attn_forms, L, spike):
+    """q/k/v as column slices of one fused buffer; one key spiked so the running max jumps mid-sequence (L = 512 / 1024: shapes the
+    software-pipelined kernel takes -- its reference maximum moves only on jumps above 2^6, so a small and two large jumps)"""
     g = torch.Generator().manual_seed(5)
-    B, h, L = 2, 2, 320
+    B, h = 2, 2
     qkv = _rand((B, L, 3 * h * 64), g).bfloat16()
-    qkv[:, 200, h * 64:2 * h * 64] *= 6.0      # large-norm key in the 4th key tile
+    qkv[:, 200, h * 64:2 * h * 64] *= spike    # large-norm key in the 4th key tile
     dq = qkv.to(cuda)
     o = ops.attention(dq[..., :h * 64], dq[..., h * 64:2 * h * 64], dq[..., 2 * h * 64:], h)
 

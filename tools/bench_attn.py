@@ -31,9 +31,14 @@ for (B, h, Lq, Lk) in [(4, 2, 4096, 4096), (4, 5, 1024, 1024), (4, 10, 256, 256)
     o = ops.attention(q, k, v, h)
     fl = 4.0 * B * h * Lq * Lk * 64
     row = []
-    for var, name in ((3, "2 groups"), (2, "4 groups"), (1, "staggered"), (4, "dbuf"), (5, "1 group"), (0, "auto")):
+    for var, name in ((3, "2 groups"), (2, "4 groups"), (1, "staggered"), (4, "dbuf"), (5, "1 group"), (6, "sw-pipelined"), (0, "auto")):
         ops.ATTN_VARIANT = var
         t = timeit(lambda: ops.attention(q, k, v, h, out=o))
         row.append(f"{name} {t:6.1f} us {fl / t / 1e6:6.1f} TF")
+    ops.ATTN_VARIANT = 6
+    o6 = ops.attention(q, k, v, h).float()
+    ops.ATTN_VARIANT = 4
+    o4 = ops.attention(q, k, v, h).float()
     ops.ATTN_VARIANT = 0
+    row.append(f"| v6 vs v4 rel-L2 {float((o6 - o4).norm() / o4.norm()):.2e}")
     print(f"B{B} h{h} Lq{Lq} Lk{Lk}: " + "   ".join(row), flush=True)

@@ -634,17 +634,14 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
       *reinterpret_cast<u32x4*>(Ks + r * 64 + sw * 8) = kreg[i];
     }
   };
+  // V is stored ROW-major like K (two 16-byte stores per thread, keys 2*krow and 2*krow + 1) and read TRANSPOSED by the hardware
+  // (ds_read_b64_tr_b16: a 16-lane group gets a 4-key x 16-d block column-major): no software transpose, no scattered 4-byte
+  // stores (they were 8 per thread and tile, several-way bank conflicts: rows of the V^T image are bank-aligned).  Chunk c of key
+  // r sits at chunk c ^ 4*((r >> 1) & 1): the four keys of a block then cover disjoint 64-byte spans of the 256-byte bank line.
   auto store_v = [&](const u32x4 (&vreg)[2], int buf) {
-    __bf16* Vt = kv_base + buf * KV_ELEMS + 64 * 64;
-    const int pos = vt_pos(2 * krow);
+    __bf16* Vs = kv_base + buf * KV_ELEMS + 64 * 64;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int d = chunk * 8 + e;
-      const int sw = (pos >> 3) ^ ((d >> 1) & 7);
-      const uint32_t a = vreg[0][e >> 1], bb = vreg[1][e >> 1];
-      const uint32_t w = (e & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
-      *reinterpret_cast<uint32_t*>(Vt + d * 64 + sw * 8 + (pos & 7)) = w;
-    }
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(Vs + (2 * krow + i) * 64 + ((chunk ^ ((krow & 1) << 2)) * 8)) = vreg[i];
   };
   f32x16 oacc[2];
 #pragma unroll
@@ -674,13 +671,25 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
       kf[j] = *reinterpret_cast<const bf16x8*>(Ks + r_ * 64 + sw * 8);
     }
   };
+  // V^T fragment j = (t, s2, u): lane (hh, gb = (lane >> 4) & 1, q_ = (lane >> 2) & 3, p_ = lane & 3) addresses key
+  // 32t + 16s2 + 4hh + q_ (+ 8 for the second half), d = 32u + 16gb + 4p_ and receives V[32t + 16s2 + 4hh + {0..3} (+8)][32u + 16gb + (lane & 15)]
+  // -- element j of the operand <-> key (j & 3) + 8 (j >> 2) + 4hh of the 16-key slot, the order the P fragments are in
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const int tr_q = (lane >> 2) & 3, tr_p = lane & 3, tr_gb = (lane >> 4) & 1;
+  int tr_off[2];                                    // element offset inside a V buffer for u = 0, 1 at (t, s2) = (0, 0), first half
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    tr_off[u] = (4 * hh + tr_q) * 64 + (4 * (u ^ (tr_q >> 1)) + 2 * tr_gb + (tr_p >> 1)) * 8 + 4 * (tr_p & 1);
   auto read_v = [&](bf16x8 (&vf)[8], int buf) {
-    const __bf16* Vt = kv_base + buf * KV_ELEMS + 64 * 64;
+    const __bf16* Vs = kv_base + buf * KV_ELEMS + 64 * 64;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int d = 32 * (j & 1) + lq;
-      const int sw = (4 * (j >> 2) + 2 * ((j >> 1) & 1) + hh) ^ ((d >> 1) & 7);
-      vf[j] = *reinterpret_cast<const bf16x8*>(Vt + d * 64 + sw * 8);
+      const __bf16* a = Vs + tr_off[j & 1] + (32 * (j >> 2) + 16 * ((j >> 1) & 1)) * 64;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 8 * 64));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      vf[j] = __builtin_bit_cast(bf16x8, both);
     }
   };
   // one tile: scores of the NEXT tile (K buffer kbuf) into nxt while the softmax of cur runs; P.V of cur (V buffer vbuf) while
@@ -715,17 +724,8 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
         pf[q][j] = (__bf16)e;
       }
     };
-    // one d of the transposed V(i+1) image
-    __bf16* Vst = kv_base + vst * KV_ELEMS + 64 * 64;
-    const int pos = vt_pos(2 * krow);
-    auto stage_v = [&](int j) {
-      if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 4)) {
-        const int d = chunk * 8 + j;
-        const int sw = (pos >> 3) ^ ((d >> 1) & 7);
-        const uint32_t a = vreg[0][j >> 1], bb = vreg[1][j >> 1];
-        const uint32_t w = (j & 1) ? ((a >> 16) | (bb & 0xffff0000u)) : ((a & 0xffffu) | (bb << 16));
-        *reinterpret_cast<uint32_t*>(Vst + d * 64 + sw * 8 + (pos & 7)) = w;
-      }
+    auto stage_v = [&]() {
+      if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 4)) store_v(vreg, vst);      // V(i+1) over V(i-1)
     };
     // A: running maximum (2 slots of 16 scores) next to score MFMAs 0, 1
     float mx = -INFINITY;
@@ -765,10 +765,10 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
     qk(2); exp4(0, 0); APTP_SLOT_END();
     qk(3); exp4(0, 1); APTP_SLOT_END();
     APTP_ATTN_STAMP(3);
-    // C1-C3: P fragment q next to the P.V MFMAs of fragment q - 1
+    // C1-C3: P fragment q next to the P.V MFMAs of fragment q - 1 and one more score MFMA
 #pragma unroll
     for (int q = 1; q < 4; ++q) {
-      pv(2 * q - 2); exp4(q, 0); APTP_SLOT_END();
+      pv(2 * q - 2); qk(3 + q); exp4(q, 0); APTP_SLOT_END();
       pv(2 * q - 1); exp4(q, 1); APTP_SLOT_END();
     }
     APTP_ATTN_STAMP(4);
@@ -776,13 +776,9 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
     halves(rs, slo, shi);
     l_run = l_run * alpha + (slo + shi);
     m_run = m_new;
-    // D: the last two P.V MFMAs and score MFMAs 4-7 next to the transposed store of V(i+1) (one d per slot), K(i+2) and the requests
-    pv(6); stage_v(0); stage_v(1); APTP_SLOT_END();
-    pv(7); stage_v(2); if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 4)) store_k(kreg, kst); APTP_SLOT_END();      // K(i+2) over K(i) (past the end: a clamped copy nobody reads)
-    qk(4); stage_v(3); stage_v(4); APTP_SLOT_END();
-    qk(5); stage_v(5); APTP_SLOT_END();
-    qk(6); stage_v(6); stage_v(7); APTP_SLOT_END();
-    qk(7);
+    // D: the last two P.V MFMAs and the last score MFMA next to the LDS stores of V(i+1) and K(i+2)
+    pv(6); stage_v(); APTP_SLOT_END();
+    pv(7); qk(7); if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 4)) store_k(kreg, kst);      // K(i+2) over K(i) (past the end: a clamped copy nobody reads)
     APTP_ATTN_STAMP(5);
     if constexpr (WITH_NEXT && !(APTP_ATTN_ABL & 2)) __syncthreads();
     APTP_ATTN_STAMP(6);

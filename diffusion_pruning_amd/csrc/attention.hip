@@ -185,10 +185,14 @@ __global__ __launch_bounds__(256 * NG) void attn_fwd_kernel(const AttnK p) {
     if (tile * 64 + 64 <= p.Lk) {              // full tile (wave-uniform): no key masking
       // v_max3_f32 directly: fmaxf() on MFMA results makes hipcc canonicalise every operand first (v_max_f32 x, x),
       // 56 instructions for 32 scores instead of 16
+      // (hipcc's hazard recognizer does not look into inline asm: one compiler-visible read of each accumulator first, so that
+      //  the wait states an MFMA result needs are inserted in front of it -- see attn_fwd_sp_kernel, where their absence was a race)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        mx = fmaxf(mx, sacc[t][0]);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sacc[t][r]), "v"(sacc[t][r + 1]));
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -732,6 +736,11 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       qk(j);
+      // The asm below reads MFMA results, and hipcc's hazard recognizer does not look into inline asm: cur[1]'s last writer (score
+      // MFMA 7, which the scheduler sinks to the top of this tile) was 3 MFMAs + ~20 instructions upstream of the first v_max3 on
+      // its registers and no wait states were inserted -- outputs changed from run to run.  One compiler-visible read of the
+      // accumulator first: the required wait states are inserted in front of it.
+      mx = fmaxf(mx, cur[j][0]);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         float v8[8];
@@ -749,10 +758,10 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
     float mlo, mhi;
     halves(mx, mlo, mhi);
     mx = fmaxf(mlo, mhi) * p.c;
-    // The reference maximum moves only when the tile's maximum exceeds it by more than 2^6: P then stays <= 64 (exact in bf16's
-    // range, row sums <= 64 * Lk in fp32) and O is rescaled -- 16 packed multiplies, ~20 % of a tile's vector work -- only in the
-    // first tiles of a row instead of in nearly every tile (any tile in which one of the wave's 32 queries sees a new maximum).
-    m_new = mx > m_run + 6.0f ? mx : m_run;
+    // (A deferred reference maximum -- moved only on jumps above 2^6, so that O is rescaled in the first tiles of a row only -- was
+    //  3.5 % faster and is NOT used: the largest P of a tile is then no longer exactly 1.0, its bf16 rounding error is not cancelled
+    //  by the unrounded row sum, and the full-size gate-gradient test's error rose from 1.1e-2 to 3.5e-2.)
+    m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     if (!__all(alpha == 1.0f)) {
 #pragma unroll

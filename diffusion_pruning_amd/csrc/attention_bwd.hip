@@ -10,7 +10,8 @@
 // MFMA operand plumbing is the forward kernel's: the "row on the lane" product is computed transposed
 // (mfma_f32_32x32x16_bf16 with the LDS tile as A operand and register-resident fragments as B operand), so each lane
 // owns ONE query (dQ kernel) or ONE key (dK/dV kernel) and the score accumulator, converted to bf16, is directly the
-// B operand of the following product; the transposed LDS images use the same 16-row permutation as the forward's V^T.
+// B operand of the following product; the second view of an operand tile (d on the MFMA row index) is a hardware-transposed read
+// of the same row-major LDS image (ds_read_b64_tr_b16), in the 16-row order the accumulators hold their rows in.
 #include "aptp_common.h"
 
 namespace {
@@ -31,11 +32,6 @@ struct AttnBwdK {
   float scale, c;                   // c = scale * log2(e)
   float* part; int nsplit;          // dK/dV kernel: query range split over nsplit workgroups, fp32 partials [nsplit][B][H][Lk][128]
 };
-
-__device__ __forceinline__ int perm16(int idx) {   // o = 8a + 4h + c  ->  8h + 4a + c inside each group of 16
-  const int o = idx & 15;
-  return (idx & ~15) | ((o & 4) << 1) | ((o & 8) >> 1) | (o & 3);
-}
 
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnBwdK p) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,26 +54,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnBwdK p) {
   p.delta[((int64_t)b * p.H + h) * p.Lq + q] = acc;
 }
 
-// stage a [64 rows][64 d] tile held as row pairs (2*pair, 2*pair+1; 16-byte chunk `chunk`) into
-//   rm: row-major image, chunks XOR-swizzled by (row>>1)&7      (A operand with rows on the MFMA row index)
-//   tr: transposed image [d][perm16(row)], chunks XOR-swizzled by (d>>1)&7   (A operand with d on the MFMA row index)
-__device__ __forceinline__ void stage_tile(__bf16* rm, __bf16* tr, const u32x4 r0, const u32x4 r1, int pair, int chunk) {
-  const int sw = chunk ^ (pair & 7);
-  if (rm) {
-    *reinterpret_cast<u32x4*>(rm + (2 * pair) * 64 + sw * 8) = r0;
-    *reinterpret_cast<u32x4*>(rm + (2 * pair + 1) * 64 + sw * 8) = r1;
-  }
-  if (tr) {
-    const int pos = perm16(2 * pair);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int d = chunk * 8 + e;
-      const int swt = (pos >> 3) ^ ((d >> 1) & 7);
-      const uint32_t a = r0[e >> 1], b = r1[e >> 1];
-      const uint32_t w = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-      *reinterpret_cast<uint32_t*>(tr + d * 64 + swt * 8 + (pos & 7)) = w;
-    }
-  }
+// One row-major LDS image per operand tile serves BOTH MFMA views (round 4; the second, software-transposed image with its eight
+// scattered 4-byte stores per thread is gone): [64 rows][64 d], 16-byte chunk c of row r at chunk c ^ xs_row(r).
+//   rows on the MFMA row index:  ds_read_b128 (frag_rm)       -- the 8 even rows of a lane group have distinct xs_row: conflict-free
+//   d on the MFMA row index:     ds_read_b64_tr_b16 (frag_trh) -- the 4 rows of a block cover disjoint 64-byte spans of the bank line
+__device__ __forceinline__ int xs_row(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// stage a [64 rows][64 d] tile held as row pairs (2*pair, 2*pair+1; 16-byte chunk `chunk`)
+__device__ __forceinline__ void stage_tile(__bf16* rm, const u32x4 r0, const u32x4 r1, int pair, int chunk) {
+  const int sw = chunk ^ xs_row(2 * pair);          // (rows 2p and 2p+1 share xs_row)
+  *reinterpret_cast<u32x4*>(rm + (2 * pair) * 64 + sw * 8) = r0;
+  *reinterpret_cast<u32x4*>(rm + (2 * pair + 1) * 64 + sw * 8) = r1;
 }
 
 __device__ __forceinline__ u32x4 load_row16(const __bf16* base, int64_t stride, int row, int nrows, int chunk) {
@@ -86,19 +73,31 @@ __device__ __forceinline__ u32x4 load_row16(const __bf16* base, int64_t stride, 
   return row < nrows ? v : (u32x4){0u, 0u, 0u, 0u};
 }
 
-// A-operand fragment of a row-major image: lane (row = base + lq, hh), k-step s -> chunk 2s + hh
+// A-operand fragment of the image with ROWS on the MFMA row index: lane (row = base + lq, hh), k-step s -> chunk 2s + hh
 __device__ __forceinline__ bf16x8 frag_rm(const __bf16* img, int row, int s, int hh) {
-  const int sw = (2 * s + hh) ^ ((row >> 1) & 7);
+  const int sw = (2 * s + hh) ^ xs_row(row);
   return *reinterpret_cast<const bf16x8*>(img + row * 64 + sw * 8);
 }
-// A-operand fragment of a transposed image: lane (d = base + lq, hh), sub-tile t (32 rows), k-step s2 (16 rows)
-__device__ __forceinline__ bf16x8 frag_tr(const __bf16* img, int d, int t, int s2, int hh) {
-  const int sw = (4 * t + 2 * s2 + hh) ^ ((d >> 1) & 7);
-  return *reinterpret_cast<const bf16x8*>(img + d * 64 + sw * 8);
+// A-operand fragment of the same image with d on the MFMA row index (d = 32u + (lane & 31)), k = the 16 rows of slot (t, s2) in
+// the order the score accumulators hold them: element j <-> row 32t + 16s2 + (j & 3) + 8(j >> 2) + 4hh.  Two hardware-transposed
+// reads: lane (hh, gb = (lane >> 4) & 1, q_ = (lane >> 2) & 3, p_ = lane & 3) addresses row 32t + 16s2 + 4hh + q_ (+ 8), columns
+// 32u + 16gb + 4p_ .. +3 and receives column 32u + 16gb + (lane & 15) of the block's four rows.  EXEC must be all ones.
+__device__ __forceinline__ bf16x8 frag_trh(const __bf16* img, int u, int t, int s2, int lane) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const int q_ = (lane >> 2) & 3, p_ = lane & 3, gb = (lane >> 4) & 1, hh = lane >> 5;
+  const int row = 32 * t + 16 * s2 + 4 * hh + q_;
+  const int ch = 4 * u + 2 * gb + (p_ >> 1);
+  const __bf16* a0 = img + row * 64 + ((ch ^ xs_row(row)) * 8) + 4 * (p_ & 1);
+  const __bf16* a1 = img + (row + 8) * 64 + ((ch ^ xs_row(row + 8)) * 8) + 4 * (p_ & 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, both);
 }
 
 __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnBwdK p) {
-  __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * 64], Kt[64 * 64], Vs[64 * 64];
+  __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * 64], Vs[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -143,8 +142,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnBwdK p) {
   load_kv(0);
   for (int tile = 0; tile < ntiles; ++tile) {
     __syncthreads();
-    stage_tile(Ks, Kt, kr[0], kr[1], pair, chunk);
-    stage_tile(Vs, nullptr, vr[0], vr[1], pair, chunk);
+    stage_tile(Ks, kr[0], kr[1], pair, chunk);
+    stage_tile(Vs, vr[0], vr[1], pair, chunk);
     __syncthreads();
     if (tile + 1 < ntiles) load_kv(tile + 1);
 #pragma unroll
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnBwdK p) {
         for (int j = 0; j < 8; ++j) dsf[j] = (__bf16)sacc[8 * s2 + j];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-          dqacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, 32 * u + lq, t, s2, hh), dsf, dqacc[u], 0, 0, 0);
+          dqacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trh(Ks, u, t, s2, lane), dsf, dqacc[u], 0, 0, 0);
       }
     }
   }
@@ -189,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnBwdK p) {
   }
 }
 
-__global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
-  __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * 64], Qt[64 * 64], Ds[64 * 64], Dt[64 * 64];
+__global__ __launch_bounds__(256, 2) void attn_dkdv_kernel(const AttnBwdK p) {
+  __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * 64], Ds[64 * 64];
   __shared__ __attribute__((aligned(16))) float lse_s[64], delta_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane & 31, hh = lane >> 5;
@@ -244,8 +243,8 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
   if (tile0 < ntiles) load_q(tile0);
   for (int tile = tile0; tile < ntiles; ++tile) {
     __syncthreads();
-    stage_tile(Qs, Qt, qr[0], qr[1], pair, chunk);
-    stage_tile(Ds, Dt, dr[0], dr[1], pair, chunk);
+    stage_tile(Qs, qr[0], qr[1], pair, chunk);
+    stage_tile(Ds, dr[0], dr[1], pair, chunk);
     if (tid < 64) lse_s[tid] = sreg;
     else if (tid < 128) delta_s[tid - 64] = sreg;
     __syncthreads();
@@ -282,8 +281,8 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(const AttnBwdK p) {
         for (int j = 0; j < 8; ++j) { pf[j] = (__bf16)pacc[8 * s2 + j]; dsf[j] = (__bf16)sacc[8 * s2 + j]; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          dvacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Dt, 32 * u + lk, t, s2, hh), pf, dvacc[u], 0, 0, 0);
-          dkacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 32 * u + lk, t, s2, hh), dsf, dkacc[u], 0, 0, 0);
+          dvacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trh(Ds, u, t, s2, lane), pf, dvacc[u], 0, 0, 0);
+          dkacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trh(Qs, u, t, s2, lane), dsf, dkacc[u], 0, 0, 0);
         }
       }
     }

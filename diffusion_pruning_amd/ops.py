@@ -347,7 +347,7 @@ GN_DEFAULT_VARIANT = 0
 GN_STATS_ONE_LAUNCH = True     # keep_stats on the small maps through the one-launch kernel (False: always three launches; A/B, tests)
 
 # AptpAttentionParams.variant for every launch (1 = staggered wave groups: A/B timing, tests of both forms)
-ATTN_VARIANT = 0
+ATTN_VARIANT = int(os.environ.get("APTP_ATTN_VARIANT", "0"))      # AptpAttentionParams.variant: 0 = the library chooses (A/B timing, tests)
 
 # GroupNorm on the large maps: True lets the last statistics workgroup of a sample finalise mean / rstd (two launches
 # instead of three).  Measured SLOWER on MI355X (162.5 vs 164.7 steps/s: 128 tickets on one counter + the acquire cost

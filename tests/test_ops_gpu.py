@@ -822,6 +822,34 @@ def test_attention(ops, cuda, case, both_attn_forms):
     assert e <= 6e-3, f"rel-L2 {e:.3e}"   # P is rounded to bf16 before P.V (as any bf16 flash kernel does)
 
 
+@pytest.mark.parametrize("case", [(1, 5, 4096), (2, 10, 1024), (2, 20, 256), (4, 2, 4096)])
+def test_attention_software_pipelined_kernel_is_race_free_and_equals_the_double_buffered_kernel(ops, cuda, case):
+    """attn_fwd_sp_kernel (what `auto` takes on whole 128-blocks) hand-places MFMAs between the softmax instructions; its running
+    maximum is inline asm (v_max3_f32) and hipcc's hazard recognizer does not look into inline asm -- a first version read MFMA
+    results too early and its outputs changed from run to run.  Twenty repeats on the same operands must agree bit for bit, output
+    and log-sum-exp, and equal the double-buffered kernel's (same arithmetic in the same order); backward: repeats agree bit for bit."""
+    B, h, L = case
+    g = torch.Generator().manual_seed(B * 1000 + h)
+    q, k, v, do = ((_rand((B, L, h * 64), g) * a).bfloat16().to(cuda) for a in (2.0, 2.0, 1.0, 1.0))
+    ops.ATTN_VARIANT = 4
+    try:
+        lse4 = torch.zeros(B, h, L, device=cuda)
+        o4 = ops.attention(q, k, v, h, lse=lse4)
+    finally:
+        ops.ATTN_VARIANT = 0
+    dq0 = dk0 = dv0 = None
+    for it in range(20):
+        lse = torch.zeros(B, h, L, device=cuda)
+        o = ops.attention(q, k, v, h, lse=lse)
+        assert torch.equal(o, o4) and torch.equal(lse, lse4), f"repeat {it}: {int((o != o4).sum())} outputs, {int((lse != lse4).sum())} lse differ"
+        if it % 5 == 0:
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            ops.attention_bwd(q, k, v, o4, do, lse4, h, dq, dk, dv)
+            if dq0 is None:
+                dq0, dk0, dv0 = dq, dk, dv
+            assert torch.equal(dq, dq0) and torch.equal(dk, dk0) and torch.equal(dv, dv0)
+
+
 @pytest.mark.parametrize("L,spike", [(320, 6.0), (512, 6.0), (512, 1.6), (1024, 30.0)])
 def test_attention_fused_qkv_views_and_spike(ops, cuda, both_attn_forms, L, spike):
     """q/k/v as column slices of one fused buffer; one key spiked so the running max jumps mid-sequence (L = 512 / 1024: shapes the

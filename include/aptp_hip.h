@@ -305,8 +305,10 @@ typedef struct {
                     * K/V; measured slower than the lock-step form, kept for testing / A-B timing); 2 = force four key-range
                     * groups (16 waves); 3 = force two lock-step groups with single-buffered K/V (two barriers per key tile);
                     * 4 = force two lock-step groups with double-buffered K/V (one barrier per key tile; auto from 32 key
-                    * tiles); 5 = force the 4-wave kernel (one group).  An explicit variant overrides the occupancy rule
-                    * that otherwise chooses between one and two groups */
+                    * tiles); 5 = force the 4-wave kernel (one group); 6 = the software-pipelined two-group kernel (round 4:
+                    * scores of key tile i+1 next to the softmax of tile i, V read transposed in hardware), which is also
+                    * what auto takes whenever Lq % 128 == 0, Lk % 128 == 0, Lk >= 256 -- bit-identical to variant 4.
+                    * An explicit variant overrides the occupancy rule that otherwise chooses between one and two groups */
   int32_t io_f32;  /* fp32 PARITY path: q, k, v, o are fp32 (strides in elements), no lse (csrc/parity_f32.hip) */
 } AptpAttentionParams;
 

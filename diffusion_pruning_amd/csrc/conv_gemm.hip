@@ -284,6 +284,9 @@ __device__ uint4 g_zero_page[512];
 //         hands its accumulators to copy 0 through LDS and retires (s_barrier counts surviving waves only), copy 0 runs the
 //         epilogue.  Twice the waves per SIMD on the same operand traffic, for the small tiles whose waves otherwise sit
 //         alone on their SIMD between DMA issue, LDS reads and MFMAs.
+#ifndef APTP_IL
+#define APTP_IL 0
+#endif
 template <int BM, int BN, int WM, int WN, int STAGES, bool PP = false, int KU = 1, int KS = 1>
 __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const KParams p) {
   constexpr int NW = WM * WN;                 // waves of one compute grid
@@ -664,6 +667,94 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void conv_gemm_dma_kernel(const 
       asm volatile("" ::: "memory");
       APTP_PHASE(1);
       int cur = 0, nxt = D;          // stage of tile kt, stage of tile kt+D
+#if APTP_IL
+      // Interleaved K-step (experiment, -DAPTP_IL=1): hipcc emits a K-step as [all LDS-DMA instructions][fragment reads][MFMAs], and
+      // a DMA instruction blocks the in-order wave while the CU's 64 B/clk load path is busy -- the load path, the LDS read port and
+      // the matrix pipe take turns.  Here the wave's DMA pieces of tile kt+D and the fragment reads of the second 32-wide half are
+      // placed BETWEEN the MFMAs, by hand, pinned with sched_barrier(0).
+      if constexpr (KS == 1) {
+        constexpr int NP = A_PASS + B_PASS, NM = 2 * MF * NF;
+        auto piece = [&](int q, int buf) {
+          const bool seg2 = l_ky >= p.KH;
+          const bool last_cc = l_cc == (seg2 ? p.ncc2 : p.ncc) - 1;
+          const bool tb = seg2 ? tail_bad2 : tail_bad;
+          if (q < A_PASS) {
+            const int i = q;
+            if (wave * 8 + RPP * i < BM) {
+              const char* src = (last_cc && tb) ? zpage : a_ptr[i];
+              __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + (buf * BM + wave * 8 + RPP * i) * BK), 16, 0, 0);
+            }
+            a_ptr[i] += BK * 2;
+          } else {
+            const int i = q - A_PASS;
+            if (wave * 8 + RPP * i < BN)
+              __builtin_amdgcn_global_load_lds((gbl_ptr)b_ptr[i], (lds_ptr)(Bs + (buf * BN + wave * 8 + RPP * i) * BK), 16, 0, 0);
+            b_ptr[i] += BK * 2;
+          }
+        };
+        auto next_tap = [&]() {
+          const bool seg2 = l_ky >= p.KH;
+          if (++l_cc == (seg2 ? p.ncc2 : p.ncc)) {
+            l_cc = 0;
+            if (++l_kx == p.KW || seg2) { l_kx = 0; ++l_ky; }
+            set_tap(0);
+          }
+        };
+        auto frags = [&](int buf, int sh, bf16x8 (&af)[MF], bf16x8 (&wf)[NF]) {
+#pragma unroll
+          for (int i = 0; i < MF; ++i) {
+            const int r = wm * WTM + i * 16 + frow;
+            af[i] = *reinterpret_cast<const bf16x8*>(As + (buf * BM + r) * BK + ((sh * 4 + fq) ^ ((r >> 1) & 7)) * 8);
+          }
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int r = wn * WTN + j * 16 + frow;
+            wf[j] = *reinterpret_cast<const bf16x8*>(Bs + (buf * BN + r) * BK + ((sh * 4 + fq) ^ ((r >> 1) & 7)) * 8);
+          }
+        };
+        for (int kt = 0; kt < n; ++kt) {
+          const bool issue = kt + D < n;
+          bf16x8 af0[MF], wf0[NF], af1[MF], wf1[NF];
+          frags(cur, 0, af0, wf0);
+          if (issue) {
+            int m = 0;
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+              for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j, ++m) {
+                  if (sh == 0 && m == 1) frags(cur, 1, af1, wf1);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh ? wf1[j] : wf0[j], sh ? af1[i] : af0[i], acc[i][j], 0, 0, 0);
+                  if ((m + 1) * NP / NM > m * NP / NM) piece(m * NP / NM, nxt);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+            next_tap();
+          } else {
+            frags(cur, 1, af1, wf1);
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+              for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh ? wf1[j] : wf0[j], sh ? af1[i] : af0[i], acc[i][j], 0, 0, 0);
+          }
+          asm volatile("" ::: "memory");
+          if (issue) {
+            if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_HI * (D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD_LO * (D - 1)) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          cur = cur + 1 == STAGES ? 0 : cur + 1;
+          nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        }
+      } else
+#endif
       for (int kt = 0; kt < n; ++kt) {
         const bool issue = kt + D < n;
         APTP_STAMP(0);

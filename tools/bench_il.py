@@ -38,6 +38,8 @@ for rec in log:
     u = uniq.setdefault(key, {"p": p, "n": 0, "flops": rec["flops"]})
     u["n"] += 1
 ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+SPLIT = "--split" in sys.argv      # also: 2-stage / ring-3 tiles with MORE K-slices than the table (two workgroups per CU instead of one)
+counters = ops._tile_counters(dev)
 tot_inc = tot_best = 0.0
 rows = []
 for key, u in uniq.items():
@@ -54,6 +56,21 @@ for key, u in uniq.items():
         us = time_launch(lib, q)
         if us is not None and us < best[0]:
             best = (us, tl)
+    if SPLIT:
+        nK = p0.KH * p0.KW * (p0.cin_pad // 64) + ((p0.cin2_pad // 64) if p0.x2 else 0)
+        for tl in (19, 28, 8, 14, 10, 16, 7, 13, 21, 30):
+            for sk in (2, 3, 4, 6):
+                if sk <= p0.split_k or nK // sk < 3:
+                    continue
+                q = clone_params(p0)
+                q.tile, q.split_k = tl, sk
+                q.workspace = ws.data_ptr()
+                q.tile_counters = counters.data_ptr()
+                if lib.aptp_conv_gemm_workspace_bytes(ctypes.byref(q)) > ws.numel() or lib.aptp_conv_gemm_tiles(ctypes.byref(q)) > 4096:
+                    continue
+                us = time_launch(lib, q)
+                if us is not None and us < best[0]:
+                    best = (us, f"{tl} s{sk} in-kernel")
     rows.append((t_inc * u["n"], key, u["n"], t_inc, p0.tile, p0.split_k, best))
     tot_inc += t_inc * u["n"]
     tot_best += best[0] * u["n"]

@@ -809,11 +809,6 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const AttnK p) {
   load_k(kra, t_begin + 2); load_v(vra, t_begin + 1);
   __syncthreads();                                  // every wave has read K(0): its buffer may be overwritten from here on
 
-#ifdef APTP_ATTN_PRIO
-  // (experiment: static priority for the younger key-range group -- the older four waves win VALU arbitration on every segment and
-  //  then wait for the others at the tile barrier)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(APTP_ATTN_PRIO);
-#endif
   // step i: S(i+1) next to softmax(i); P.V(i) next to staging K(i+2) -> K buffer i&1, V(i+1) -> V buffer (i+1)&1, then K(i+3), V(i+2) requested
   auto body = [&](int i, f32x16 (&cur)[2], f32x16 (&nxt)[2], u32x4 (&k0)[2], u32x4 (&v0)[2], u32x4 (&k1)[2], u32x4 (&v1)[2]) {
     tile_step(std::true_type{}, cur, nxt, (i + 1) & 1, i & 1, i & 1, (i + 1) & 1, t_begin + i + 3, t_begin + i + 2, k0, v0, k1, v1);

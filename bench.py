@@ -44,6 +44,7 @@ Prints ONE JSON line (see the task contract) with extra objects:
                   torch.matmul, and this repo's own kernel) and a 1 GiB device copy; per_tile = the same fraction for each
                   kernel instantiation.
   roofline_groupnorm  HBM roofline of the GroupNorm(+SiLU) family: algorithmic bytes (x read once + y written once) / time.
+  roofline_attention  MFMA roofline of the attention launches of one forward (4 B h Lq Lk 64 FLOP each), self- and cross-attention apart.
   gpu_vendor_baseline  the oracle's op sequence on this GPU in bf16 through torch-ROCm's own libraries (MIOpen / hipBLASLt / SDPA),
                   gated semantics, HIP-graph replay (tools/bench_vendor.py, child process): a stated yardstick, not the target.
   cpu_baseline    the oracle (PyTorch CPU restatement, fp32) timed on this host's cores on a bounded sample: median of 5
@@ -272,7 +273,7 @@ def run_infer(R: Rank):
     def step():
         return model(sample, t, ehs, return_dict=False)[0]
 
-    roofline = roofline_gn = cpu_baseline = vendor_baseline = None
+    roofline = roofline_gn = roofline_attn = cpu_baseline = vendor_baseline = None
     with torch.no_grad():
         out = step()                      # builds the packed-weight plans
         R.sync()
@@ -309,6 +310,7 @@ def run_infer(R: Rank):
             if R.world == 1:
                 roofline["peak_measured"] = measure_peaks(ops, dev)
             roofline_gn = measure_gn_roofline(ops, step, dev)
+            roofline_attn = measure_attn_roofline(ops, step, dev)
             if R.world == 1 and not args.no_cpu_baseline:
                 cpu_baseline = measure_cpu_baseline(model, args.dense)
             if R.world == 1 and not args.no_vendor_baseline and L == 64:
@@ -365,7 +367,7 @@ def run_infer(R: Rank):
                                f"(512x512), bs={B}/GPU, {what}, seeded random-init weights, HIP graph replay",
                    "global_batch": B * R.world, "parallelism": f"replicas x{R.world} (no data-path collective)"},
         "per_gpu_steps_per_s": round(value / R.world, 3),
-        "roofline": roofline, "roofline_groupnorm": roofline_gn, "cpu_baseline": cpu_baseline,
+        "roofline": roofline, "roofline_groupnorm": roofline_gn, "roofline_attention": roofline_attn, "cpu_baseline": cpu_baseline,
         "gpu_vendor_baseline": vendor_baseline,
         "sustained": sustained, "extra_configs": extra_configs,
     }
@@ -829,6 +831,45 @@ def measure_gn_roofline(ops, step, dev):
     return {"bound": "hbm", "kernel": "aptp_groupnorm family (gn_group / gn_stats / gn_finalize* / gn_apply)", "achieved": round(gbs, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
             "calls_per_step": len(log), "family_ms_per_step": round(ms, 4), "algorithmic_MB_per_step": round(nbytes / 1e6, 1)}
+
+
+def measure_attn_roofline(ops, step, dev):
+    """MFMA roofline of the attention launches of one forward (aptp_attention: flash-style, head_dim 64), replayed from a HIP graph on
+    their recorded operands; self-attention (Lk = Lq) and cross-attention (77 keys) apart."""
+    import torch
+    lib = ops._lib.load()
+    ops.ATTN_LAUNCH_LOG = []
+    step()
+    torch.cuda.synchronize()
+    log, ops.ATTN_LAUNCH_LOG = ops.ATTN_LAUNCH_LOG, None
+    if not log:
+        return None
+    stream = torch.cuda.Stream()
+
+    def timed(recs):
+        def fn():
+            s = torch.cuda.current_stream().cuda_stream
+            for rec in recs:
+                rc = lib.aptp_attention(ctypes.byref(rec["params"]), s)
+                assert rc == 0
+        ms = _time_graph(torch, stream, fn)
+        fl = sum(r["flops"] for r in recs)
+        tf = fl / (ms * 1e-3) / 1e12
+        return {"launches": len(recs), "ms": round(ms, 4), "algorithmic_gflop": round(fl / 1e9, 1), "tflops": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+    allr = timed(log)
+    out = {"bound": "mfma", "kernel": "aptp_attention (attn_fwd_sp_kernel on whole 128-blocks, attn_fwd_kernel<NG> otherwise)", "achieved": allr["tflops"],
+           "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": allr["frac"], "traffic": None, "calls_per_step": allr["launches"],
+           "family_ms_per_step": allr["ms"], "algorithmic_gflop_per_step": allr["algorithmic_gflop"]}
+    self_a = [r for r in log if r["Lk"] == r["params"].Lq]
+    cross = [r for r in log if r["Lk"] != r["params"].Lq]
+    if self_a:
+        out["self_attention"] = timed(self_a)
+        big = [r for r in self_a if r["Lk"] >= 4096]
+        if big:
+            out["self_attention_level64"] = timed(big)
+    if cross:
+        out["cross_attention"] = timed(cross)
+    return out
 
 
 def measure_peaks(ops, dev):

@@ -275,6 +275,7 @@ def tuning_lookup(M, N, Cin, taps, stride, ups, geglu, Cin2: int = 0):
 LAUNCH_LOG = None
 # Same for aptp_groupnorm calls (bench.py's HBM roofline leg): {"params", "bytes": x read once + y written once, "keep"}
 GN_LAUNCH_LOG = None
+ATTN_LAUNCH_LOG = None      # bench.py: the attention launches of ONE forward (re-timed for roofline_attention)
 
 # Split-K launches combine their K-slices inside the kernel (AptpConvGemmParams.tile_counters) instead of launching
 # splitk_reduce_kernel; False restores the two-launch form (A/B timing, tests of both forms)
@@ -868,6 +869,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     if lse is not None:
         assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (B, heads, Lq)
         p.lse = lse.data_ptr()
+    if ATTN_LAUNCH_LOG is not None and not p.io_f32:
+        ATTN_LAUNCH_LOG.append({"params": p, "flops": 4.0 * B * heads * Lq * Lk * 64, "keep": (q, k, v, out, lse), "Lk": Lk})
     _lib.check(lib.aptp_attention(ctypes.byref(p), _stream()), "aptp_attention")
     return out
 

@@ -455,7 +455,7 @@ def run_train(R: Rank, steps=None, warmup=None, extras: bool = True):
         fam = family_roofline(ops, fam_log)
     return {
         "metric": "pruning-train-steps/s (APTP Pruner.step: router + dense teacher fwd + soft-masked student fwd/bwd, SD-2.1, "
-                  "64x64 latents, bs=4 per GPU; summed over data-parallel ranks)",
+                  f"{latent}x{latent} latents, bs={args.batch} per GPU; summed over data-parallel ranks)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": R.n_seen, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",

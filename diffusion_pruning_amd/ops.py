@@ -256,6 +256,8 @@ def tuning_lookup(M, N, Cin, taps, stride, ups, geglu, Cin2: int = 0):
     for (M2, N2, K2, v) in _tuning_classes().get((taps, stride, ups, int(bool(geglu)), Cin2 > 0), ()):
         if v["tile"] in _HALO_TILES and M2 != M:
             continue                      # the halo-in-LDS tiles are tied to the map width
+        if v["tile"] > 6 and max(Cin, Cin2) > 4032:
+            continue                      # every tile past the six register-staged ones is an LDS-DMA tile: channel steps <= 4032 (csrc)
         # (more rows than the tuned shape is the benign direction -- the same tile, more of them: a U-Net batch of 16 takes the
         #  entries tuned at batch 4 instead of falling back to the register-staged heuristic tiles, which bench.py's infer_bs16 leg
         #  measured at 0.08 of the MFMA peak on 48 launches)
@@ -653,7 +655,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         if tuned is not None:
             p.tile, split_k = tuned["tile"], tuned["split_k"]
             in_kernel = bool(tuned.get("in_kernel", 0))
-            if LEAN_REMAP and p.tile not in _LEAN_TILES and split_k == 1 and "insitu" not in tuned and pw.KH == 1 and pw.KW == 1 \
+            if LEAN_REMAP and p.tile not in _LEAN_TILES and split_k == 1 and "insitu" not in tuned and pw.KH == 1 and pw.KW == 1 and pw.cin_pad <= 4032 \
                     and stride == 1 and not ups and x2 is None and colgate is None and corr is None and rowbias is None \
                     and depth is None and not out_f32 and gn is None and (act != ACT_GEGLU or (residual is None and not rowstats)):
                 # a plain linear layer whose table entry (tuned before csrc/lin_gemm.hip existed: the training steps' shapes) names a

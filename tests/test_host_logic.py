@@ -287,6 +287,11 @@ def test_tuning_lookup_falls_back_to_the_nearest_tuned_shape_of_the_same_class()
     # a neighbour's split-K never leaves a slice with fewer than four K-steps
     deep = ops.tuning_lookup(256, 1280, 1200, 9, 1, 0, False)
     assert deep is not None and deep["split_k"] <= max(1, (9 * 1200 // 64) // 4)
+    # the LDS-DMA tiles (every id past the six register-staged ones) take channel steps up to 4032: a shape with more channels per tap
+    # never inherits one from a neighbour (round 4: the batch-64 training shapes put 128x160 DMA tiles next to K = 5120 linears)
+    for M in (16384, 12288, 4096 * 3):
+        wide = ops.tuning_lookup(M, 1280, 5100, 1, 1, 0, False)
+        assert wide is None or wide["tile"] <= 6, wide
 
 
 # ---- the same host logic without any rounding: fp32 storage end to end (emulator exact mode) vs the fp32 oracle -------------

@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="tune the launches of one eager pruning train step (teacher + student forward, data-gradient GEMMs) instead of the inference forward")
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64, help="--train: latent size of the recorded step (the reference trains at 32 with batch 64)")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--tiles", type=str, default="", help="comma-separated APTP_TILE_* ids: only these are candidates (with --refine: a new tile against the committed table)")
     args = ap.parse_args()
@@ -129,9 +130,9 @@ def record_train_step(args):
                                   resource_aware_normalization=False, optimal_transport=True).to(dev)
     hn.train(); qz.train()
     step = PrunerStep(unet, hn, qz)
-    step.count_macs(64)
+    step.count_macs(args.latent)
     opt = torch.optim.AdamW(step.trainable_parameters(), lr=2e-4)
-    batch = synthetic_batch(args.batch, 64, dev)
+    batch = synthetic_batch(args.batch, args.latent, dev)
     if not args.refine:
         ops.TUNING = {}
     step.train_step(opt, batch)

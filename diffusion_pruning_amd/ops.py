@@ -405,6 +405,8 @@ def _root(t: torch.Tensor) -> torch.Tensor:
 # inside a captured graph) and ustat_end() at the end; outside such a bracket nothing is emitted.  USTAT_UNIT = channels per unit:
 # it must divide every GroupNorm group size of the model (SD-2.1: 320 / 32 = 10); 0 = off.
 USTAT = os.environ.get("APTP_USTAT", "1") != "0"
+# a split-K launch whose output feeds a GroupNorm combines its slices in-kernel (and emits the statistics) up to this many slices
+COLS_SPLIT_MAX = int(os.environ.get("APTP_COLS_SPLIT_MAX", "2"))
 USTAT_NREP = int(os.environ.get("APTP_USTAT_NREP", "8"))
 _USTAT_WORDS = 1 << 17            # int64 words per arena (1 MiB): ~35 producers x 8 replicas x 4 samples x <= 128 units x 2
 _ustat_arenas = {}
@@ -706,7 +708,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         # in-kernel form up to 2 slices (beyond that it loses more than the GroupNorm statistics pass it saves: measured
         # +8 us on the 4-slice level-32 convs against a 6.5 us pass + a kernel boundary)
         want_cols = colstats and COLSTATS and Hout * Wout >= COLSTATS_MIN_HW and act != ACT_GEGLU and not out_f32 \
-            and (in_kernel or p.split_k <= 2)
+            and (in_kernel or p.split_k <= COLS_SPLIT_MAX)
         if rowstats or want_cols:
             in_kernel = True
         sk_tile = p.tile >= SK_TILE_FIRST     # persistent stream-K tiles: partial tiles are always combined in-kernel
